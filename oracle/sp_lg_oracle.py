@@ -1,0 +1,510 @@
+"""CPU oracle for the SuperPoint + LightGlue forward path.
+
+TEST INFRASTRUCTURE ONLY -- never imported by the product package
+(`glue-factory_amd/`).  Only `tests/`, `__graft_entry__.smoke()` and the
+`cpu_baseline` leg of `bench.py` may use it, and only as the checker.
+
+This is a functional restatement (fp32, PyTorch-CPU operators, no reference
+imports) of the reference's hot path:
+
+  * SuperPoint (MagicLeap layout)  /root/reference/gluefactory_nonfree/superpoint.py:202-350
+  * SuperPoint-open                /root/reference/gluefactory/models/extractors/superpoint_open.py:123-217
+  * LightGlue (in-tree)            /root/reference/gluefactory/models/matchers/lightglue.py:399-525
+  * TwoViewPipeline key plumbing   /root/reference/gluefactory/models/two_view_pipeline.py:62-90
+
+Parity pin: `tests/golden/*.npz` were produced by importing the reference
+itself in the build container (`oracle/tools/make_goldens.py`); the oracle is
+checked against them bit-for-bit on CPU in `tests/test_oracle_golden.py`.
+
+Weights are plain `dict[str, Tensor]` using the reference's state_dict key
+names, so a reference checkpoint can be fed in unchanged.
+"""
+import math
+
+import torch
+import torch.nn.functional as F
+from torch.nn.attention import SDPBackend, sdpa_kernel
+
+GRAY_WEIGHTS = (0.299, 0.587, 0.114)
+
+
+# --------------------------------------------------------------------------
+# SuperPoint
+# --------------------------------------------------------------------------
+def to_gray(image):
+    """superpoint.py:204-206 -- weighted channel sum when the input is RGB."""
+    if image.shape[1] == 3:
+        w = image.new_tensor(GRAY_WEIGHTS).view(1, 3, 1, 1)
+        image = (image * w).sum(1, keepdim=True)
+    return image
+
+
+def _conv_relu(x, W, name):
+    return F.relu(F.conv2d(x, W[name + ".weight"], W[name + ".bias"], padding=W[name + ".weight"].shape[-1] // 2))
+
+
+def sp_backbone(image, W):
+    """superpoint.py:209-219 -- 8x (conv3x3 + ReLU), 2x2 max-pool after blocks 1..3."""
+    x = image
+    for blk in (1, 2, 3, 4):
+        x = _conv_relu(x, W, f"conv{blk}a")
+        x = _conv_relu(x, W, f"conv{blk}b")
+        if blk < 4:
+            x = F.max_pool2d(x, 2, 2)
+    return x
+
+
+def _open_block(x, W, prefix, relu=True):
+    """superpoint_open.py:59-75 -- Conv -> (ReLU) -> BatchNorm(eps=1e-3), eval-mode statistics."""
+    w = W[prefix + ".conv.weight"]
+    x = F.conv2d(x, w, W[prefix + ".conv.bias"], padding=(w.shape[-1] - 1) // 2)
+    if relu:
+        x = F.relu(x)
+    return F.batch_norm(
+        x,
+        W[prefix + ".bn.running_mean"],
+        W[prefix + ".bn.running_var"],
+        W[prefix + ".bn.weight"],
+        W[prefix + ".bn.bias"],
+        training=False,
+        eps=1e-3,
+    )
+
+
+def sp_open_backbone(image, W):
+    """superpoint_open.py:94-105."""
+    x = image
+    for i in range(4):
+        x = _open_block(x, W, f"backbone.{i}.0")
+        x = _open_block(x, W, f"backbone.{i}.1")
+        if i < 3:
+            x = F.max_pool2d(x, 2, 2)
+    return x
+
+
+def logits_to_heatmap(logits, cell=8):
+    """superpoint.py:226-230 -- softmax over 65, drop the dustbin, depth-to-space."""
+    p = torch.softmax(logits, 1)[:, :-1]
+    b, _, h, w = p.shape
+    p = p.permute(0, 2, 3, 1).reshape(b, h, w, cell, cell)
+    return p.permute(0, 1, 3, 2, 4).reshape(b, h * cell, w * cell)
+
+
+def sp_dense(image, W, variant="magicleap"):
+    """Dense stage: returns (heatmap (B,8h,8w), dense descriptors (B,256,h,w))."""
+    image = to_gray(image)
+    if variant == "magicleap":
+        feat = sp_backbone(image, W)
+        logits = F.conv2d(_conv_relu(feat, W, "convPa"), W["convPb.weight"], W["convPb.bias"])
+        raw = F.conv2d(_conv_relu(feat, W, "convDa"), W["convDb.weight"], W["convDb.bias"])
+    elif variant == "open":
+        feat = sp_open_backbone(image, W)
+        logits = _open_block(_open_block(feat, W, "detector.0"), W, "detector.1", relu=False)
+        raw = _open_block(_open_block(feat, W, "descriptor.0"), W, "descriptor.1", relu=False)
+    else:
+        raise ValueError(variant)
+    dense_desc = F.normalize(raw, p=2, dim=1)
+    return logits_to_heatmap(logits), dense_desc
+
+
+def nms_heatmap(scores, radius):
+    """superpoint.py:60-80 (= superpoint_open.py:34-49).
+
+    Keeps local maxima of the (2r+1)^2 window, then twice re-admits maxima of
+    the not-yet-suppressed remainder.  Equal neighbours are all kept.
+    """
+    k = 2 * radius + 1
+
+    def pool(t):
+        return F.max_pool2d(t, kernel_size=k, stride=1, padding=radius)
+
+    zero = torch.zeros_like(scores)
+    keep = scores == pool(scores)
+    for _ in range(2):
+        suppressed = pool(keep.float()) > 0
+        rest = torch.where(suppressed, zero, scores)
+        fresh = rest == pool(rest)
+        keep = keep | (fresh & ~suppressed)
+    return torch.where(keep, scores, zero)
+
+
+def mask_borders(scores, border, image_size=None, honour_image_size=True):
+    """superpoint.py:243-254 / superpoint_open.py:147-152 -- score = -1 within `border` px of the frame.
+
+    `image_size` is (B,2) as (w,h); the MagicLeap variant masks relative to it,
+    the open variant always relative to the tensor.
+    """
+    if not border:
+        return scores
+    scores = scores.clone()
+    scores[:, :border] = -1
+    scores[:, :, :border] = -1
+    if image_size is not None and honour_image_size:
+        for i in range(scores.shape[0]):
+            w, h = image_size[i]
+            scores[i, int(h.item()) - border:] = -1
+            scores[i, :, int(w.item()) - border:] = -1
+    else:
+        scores[:, -border:] = -1
+        scores[:, :, -border:] = -1
+    return scores
+
+
+def select_keypoints(scores, threshold, max_kp):
+    """superpoint.py:257-293, :83-87 -- per image: row-major candidates > threshold, then top-k.
+
+    Returns a list of (yx int64 (n,2), score (n,)).  When n <= k the candidates
+    come back in row-major order, otherwise sorted by descending score.
+    """
+    out = []
+    for s in scores:
+        yx = torch.nonzero(s > threshold)  # row-major
+        v = s[yx[:, 0], yx[:, 1]]
+        if max_kp is not None and max_kp > 0 and max_kp < len(yx):
+            v, idx = torch.topk(v, max_kp, dim=0, sorted=True)
+            yx = yx[idx]
+        out.append((yx, v))
+    return out
+
+
+def sample_descriptors(kp_xy, dense, mode, cell=8):
+    """Bilinear descriptor lookup at integer keypoints (x,y), then L2-normalise.
+
+    mode 'legacy' : superpoint.py:117-133 (align_corners=True, shifted grid)
+    mode 'fixed'  : superpoint.py:138-149
+    mode 'open'   : superpoint_open.py:20-31
+    kp_xy (B,K,2) float, dense (B,C,h,w)  ->  (B,C,K)
+    """
+    b, c, h, w = dense.shape
+    kp = kp_xy.clone()
+    if mode == "legacy":
+        kp = kp - cell / 2 + 0.5
+        kp = kp / torch.tensor([(w * cell - cell / 2 - 0.5), (h * cell - cell / 2 - 0.5)]).to(kp)[None]
+        align = True
+    elif mode == "fixed":
+        kp = kp / (kp.new_tensor([w, h]) * cell)
+        align = False
+    elif mode == "open":
+        kp = (kp + 0.5) / (kp.new_tensor([w, h]) * cell)
+        align = False
+    else:
+        raise ValueError(mode)
+    kp = kp * 2 - 1
+    d = F.grid_sample(dense, kp.view(b, 1, -1, 2), mode="bilinear", align_corners=align)
+    return F.normalize(d.reshape(b, c, -1), p=2, dim=1)
+
+
+SP_DEFAULTS = dict(
+    variant="magicleap",
+    nms_radius=4,
+    detection_threshold=0.005,
+    max_num_keypoints=-1,
+    remove_borders=4,
+    legacy_sampling=True,
+)
+
+
+def superpoint_forward(data, W, **conf):
+    """Sparse SuperPoint forward.  Returns per-image lists plus stacked tensors when counts agree.
+
+    Output keys: keypoints (x,y)+0.5, keypoint_scores, descriptors (K,256) per image;
+    `heatmap`, `dense_descriptors` always returned for stage-wise checks.
+    """
+    cfg = {**SP_DEFAULTS, **conf}
+    variant = cfg["variant"]
+    heat, dense = sp_dense(data["image"], W, variant)
+    s = nms_heatmap(heat, cfg["nms_radius"])
+    s = mask_borders(s, cfg["remove_borders"], data.get("image_size"), honour_image_size=(variant == "magicleap"))
+    k = cfg["max_num_keypoints"]
+    sel = select_keypoints(s, cfg["detection_threshold"], None if (k is None or k <= 0) else k)
+    if variant == "open":
+        mode = "open"
+    else:
+        mode = "legacy" if cfg["legacy_sampling"] else "fixed"
+    kps, scs, descs = [], [], []
+    for i, (yx, v) in enumerate(sel):
+        xy = torch.flip(yx, [1]).float()
+        d = sample_descriptors(xy[None], dense[i:i + 1], mode)[0]
+        kps.append(xy + 0.5)
+        scs.append(v)
+        descs.append(d.t().contiguous())
+    out = {
+        "keypoints_list": kps,
+        "keypoint_scores_list": scs,
+        "descriptors_list": descs,
+        "heatmap": heat,
+        "nms_scores": s,
+        "dense_descriptors": dense,
+    }
+    if len({len(x) for x in kps}) == 1:
+        out["keypoints"] = torch.stack(kps)
+        out["keypoint_scores"] = torch.stack(scs)
+        out["descriptors"] = torch.stack(descs)
+    return out
+
+
+# --------------------------------------------------------------------------
+# LightGlue
+# --------------------------------------------------------------------------
+def normalize_keypoints(kpts, size=None):
+    """lightglue.py:22-33 -- centre on the image and divide by half the longer side."""
+    if size is None:
+        size = 1 + kpts.max(-2).values - kpts.min(-2).values
+    size = torch.as_tensor(size).to(kpts)
+    if size.dim() == 1:
+        size = size[None].expand(kpts.shape[0], -1)
+    shift = size / 2
+    scale = size.max(-1).values / 2
+    return (kpts - shift[..., None, :]) / scale[..., None, None]
+
+
+def fourier_encoding(kpts, Wr):
+    """lightglue.py:46-59 -- (2,B,1,K,64): cos/sin of Wr*kp, each frequency repeated twice."""
+    proj = F.linear(kpts, Wr)
+    emb = torch.stack([torch.cos(proj), torch.sin(proj)], 0).unsqueeze(-3)
+    return emb.repeat_interleave(2, dim=-1)
+
+
+def _rot_pairs(t):
+    """lightglue.py:36-39 -- (x0,x1) -> (-x1,x0) on consecutive pairs."""
+    a, b = t.unflatten(-1, (-1, 2)).unbind(-1)
+    return torch.stack((-b, a), -1).flatten(-2)
+
+
+def apply_rotary(enc, t):
+    return t * enc[0] + _rot_pairs(t) * enc[1]
+
+
+def _ffn(x, msg, W, p):
+    """lightglue.py:137-142 -- Linear(512,512) -> LayerNorm -> GELU(erf) -> Linear(512,256)."""
+    h = F.linear(torch.cat([x, msg], -1), W[p + ".ffn.0.weight"], W[p + ".ffn.0.bias"])
+    h = F.layer_norm(h, (h.shape[-1],), W[p + ".ffn.1.weight"], W[p + ".ffn.1.bias"], 1e-5)
+    h = F.gelu(h)
+    return F.linear(h, W[p + ".ffn.3.weight"], W[p + ".ffn.3.bias"])
+
+
+def self_block(x, enc, W, p, heads=4):
+    """lightglue.py:144-157.  Wqkv output feature = head*192 + dim*3 + {q,k,v}."""
+    qkv = F.linear(x, W[p + ".Wqkv.weight"], W[p + ".Wqkv.bias"])
+    qkv = qkv.unflatten(-1, (heads, -1, 3)).transpose(1, 2)
+    q, k, v = qkv[..., 0], qkv[..., 1], qkv[..., 2]
+    q, k = apply_rotary(enc, q), apply_rotary(enc, k)
+    # lightglue.py:101-102 -- constructing the reference with `flash: False` calls
+    # torch.backends.cuda.enable_flash_sdp(False) process-wide, so its CPU run takes SDPA's MATH path.
+    with sdpa_kernel(SDPBackend.MATH):
+        ctx = F.scaled_dot_product_attention(q.contiguous(), k.contiguous(), v.contiguous())
+    msg = F.linear(ctx.transpose(1, 2).flatten(-2), W[p + ".out_proj.weight"], W[p + ".out_proj.bias"])
+    return x + _ffn(x, msg, W, p)
+
+
+def cross_block(x0, x1, W, p, heads=4):
+    """lightglue.py:186-215 (einsum branch :200-210): one similarity, softmax along both axes."""
+    def split(t):
+        return t.unflatten(-1, (heads, -1)).transpose(1, 2)
+
+    qk0 = split(F.linear(x0, W[p + ".to_qk.weight"], W[p + ".to_qk.bias"]))
+    qk1 = split(F.linear(x1, W[p + ".to_qk.weight"], W[p + ".to_qk.bias"]))
+    v0 = split(F.linear(x0, W[p + ".to_v.weight"], W[p + ".to_v.bias"]))
+    v1 = split(F.linear(x1, W[p + ".to_v.weight"], W[p + ".to_v.bias"]))
+    s = (qk0.shape[-1] ** -0.5) ** 0.5
+    qk0, qk1 = qk0 * s, qk1 * s
+    sim = torch.einsum("bhid,bhjd->bhij", qk0, qk1)
+    a01 = torch.softmax(sim, -1)
+    a10 = torch.softmax(sim.transpose(-2, -1).contiguous(), -1)
+    m0 = torch.einsum("bhij,bhjd->bhid", a01, v1)
+    m1 = torch.einsum("bhji,bhjd->bhid", a10.transpose(-2, -1), v0)
+    m0 = F.linear(m0.transpose(1, 2).flatten(-2), W[p + ".to_out.weight"], W[p + ".to_out.bias"])
+    m1 = F.linear(m1.transpose(1, 2).flatten(-2), W[p + ".to_out.weight"], W[p + ".to_out.bias"])
+    return x0 + _ffn(x0, m0, W, p), x1 + _ffn(x1, m1, W, p)
+
+
+def log_assignment(d0, d1, W, p):
+    """lightglue.py:250-284 -- (B,M+1,N+1) log assignment with matchability bins."""
+    dim = d0.shape[-1]
+    m0 = F.linear(d0, W[p + ".final_proj.weight"], W[p + ".final_proj.bias"]) / dim ** 0.25
+    m1 = F.linear(d1, W[p + ".final_proj.weight"], W[p + ".final_proj.bias"]) / dim ** 0.25
+    sim = torch.einsum("bmd,bnd->bmn", m0, m1)
+    z0 = F.linear(d0, W[p + ".matchability.weight"], W[p + ".matchability.bias"])
+    z1 = F.linear(d1, W[p + ".matchability.weight"], W[p + ".matchability.bias"])
+    b, m, n = sim.shape
+    cert = F.logsigmoid(z0) + F.logsigmoid(z1).transpose(1, 2)
+    rows = F.log_softmax(sim, 2)
+    cols = F.log_softmax(sim.transpose(-1, -2).contiguous(), 2).transpose(-1, -2)
+    S = sim.new_zeros((b, m + 1, n + 1))
+    S[:, :m, :n] = rows + cols + cert
+    S[:, :-1, -1] = F.logsigmoid(-z0.squeeze(-1))
+    S[:, -1, :-1] = F.logsigmoid(-z1.squeeze(-1))
+    return S, sim
+
+
+def filter_matches(S, th):
+    """lightglue.py:287-303 -- mutual arg-max over the inner (M,N) block, exp(score) > th."""
+    inner = S[:, :-1, :-1]
+    r, c = inner.max(2), inner.max(1)
+    m0, m1 = r.indices, c.indices
+    i0 = torch.arange(m0.shape[1])[None]
+    i1 = torch.arange(m1.shape[1])[None]
+    mut0 = i0 == m1.gather(1, m0)
+    mut1 = i1 == m0.gather(1, m1)
+    e = r.values.exp()
+    zero = e.new_tensor(0)
+    ms0 = torch.where(mut0, e, zero)
+    ms1 = torch.where(mut1, ms0.gather(1, m1), zero)
+    ok0 = mut0 & (ms0 > th)
+    ok1 = mut1 & ok0.gather(1, m1)
+    return torch.where(ok0, m0, -1), torch.where(ok1, m1, -1), ms0, ms1, r.indices, c.indices
+
+
+LG_DEFAULTS = dict(n_layers=9, num_heads=4, filter_threshold=0.0)
+
+
+def lightglue_forward(data, W, collect_layers=(), **conf):
+    """lightglue.py:399-525 with depth/width adaptivity off (dead in every shipped config)."""
+    cfg = {**LG_DEFAULTS, **conf}
+    k0, k1 = data["keypoints0"], data["keypoints1"]
+    size0 = size1 = None
+    if "view0" in data and "view1" in data:
+        size0 = data["view0"].get("image_size")
+        size1 = data["view1"].get("image_size")
+    k0 = normalize_keypoints(k0, size0)
+    k1 = normalize_keypoints(k1, size1)
+    d0 = data["descriptors0"].contiguous()
+    d1 = data["descriptors1"].contiguous()
+    if "input_proj.weight" in W:
+        d0 = F.linear(d0, W["input_proj.weight"], W["input_proj.bias"])
+        d1 = F.linear(d1, W["input_proj.weight"], W["input_proj.bias"])
+    e0 = fourier_encoding(k0, W["posenc.Wr.weight"])
+    e1 = fourier_encoding(k1, W["posenc.Wr.weight"])
+    L, H = cfg["n_layers"], cfg["num_heads"]
+    layers = {}
+    for i in range(L):
+        p = f"transformers.{i}"
+        d0 = self_block(d0, e0, W, p + ".self_attn", H)
+        d1 = self_block(d1, e1, W, p + ".self_attn", H)
+        if ("self", i) in collect_layers:
+            layers[("self", i)] = (d0.clone(), d1.clone())
+        d0, d1 = cross_block(d0, d1, W, p + ".cross_attn", H)
+        if i in collect_layers:
+            layers[i] = (d0.clone(), d1.clone())
+    S, sim = log_assignment(d0, d1, W, f"log_assignment.{L - 1}")
+    m0, m1, ms0, ms1, am0, am1 = filter_matches(S, cfg["filter_threshold"])
+    return {
+        "matches0": m0,
+        "matches1": m1,
+        "matching_scores0": ms0,
+        "matching_scores1": ms1,
+        "ref_descriptors0": d0[:, None],
+        "ref_descriptors1": d1[:, None],
+        "log_assignment": S,
+        "prune0": torch.ones_like(ms0) * L,
+        "prune1": torch.ones_like(ms1) * L,
+        "_argmax0": am0,
+        "_argmax1": am1,
+        "_sim": sim,
+        "_layers": layers,
+    }
+
+
+# --------------------------------------------------------------------------
+# Two-view composite
+# --------------------------------------------------------------------------
+def two_view_forward(data, W_sp, W_lg, sp_conf, lg_conf):
+    """two_view_pipeline.py:62-90 -- extractor per view, keys suffixed 0/1, then the matcher."""
+    pred = {}
+    for i in ("0", "1"):
+        p = superpoint_forward(data["view" + i], W_sp, **sp_conf)
+        for k in ("keypoints", "keypoint_scores", "descriptors"):
+            pred[k + i] = p[k]
+        if sp_conf.get("variant") == "open":
+            pred["heatmap" + i] = p["heatmap"]
+    lg = lightglue_forward({**data, **pred}, W_lg, **lg_conf)
+    pred.update({k: v for k, v in lg.items() if not k.startswith("_")})
+    return pred
+
+
+# --------------------------------------------------------------------------
+# Seeded weights (same key names / shapes as the reference modules)
+# --------------------------------------------------------------------------
+def _conv_init(g, cout, cin, k, gain=1.4, bias_scale=0.05):
+    """Zero-sum filters (no DC response) with He-style gain: keeps activations O(1), ~50 % sparse and
+    spatially diverse through 10 layers, so seeded weights give peaky heatmaps and distinct descriptors."""
+    w = torch.randn(cout, cin, k, k, generator=g) * gain / math.sqrt(cin * k * k)
+    w = w - w.mean(dim=(1, 2, 3), keepdim=True)
+    b = torch.randn(cout, generator=g) * bias_scale
+    return w, b
+
+
+def make_sp_weights(seed=0, variant="magicleap"):
+    """Seeded SuperPoint weights under the reference's state_dict key names."""
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+    chans = [(1, 64), (64, 64), (64, 64), (64, 64), (64, 128), (128, 128), (128, 128), (128, 128)]
+    if variant == "magicleap":
+        names = ["conv1a", "conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b"]
+        for n, (ci, co) in zip(names, chans):
+            W[n + ".weight"], W[n + ".bias"] = _conv_init(g, co, ci, 3)
+        for n, (ci, co, k) in {"convPa": (128, 256, 3), "convPb": (256, 65, 1), "convDa": (128, 256, 3), "convDb": (256, 256, 1)}.items():
+            W[n + ".weight"], W[n + ".bias"] = _conv_init(g, co, ci, k)
+        W["conv1a.weight"] = W["conv1a.weight"] * 8.0  # images are in [0,1]
+        W["convPb.weight"] = W["convPb.weight"] * 4.0  # spread the detector logits -> real peaks
+    else:
+        def bn(prefix, c):
+            W[prefix + ".bn.weight"] = 0.75 + 0.5 * torch.rand(c, generator=g)
+            W[prefix + ".bn.bias"] = 0.2 * (torch.rand(c, generator=g) - 0.5)
+            W[prefix + ".bn.running_mean"] = 0.2 * (torch.rand(c, generator=g) - 0.3)
+            W[prefix + ".bn.running_var"] = 0.5 + torch.rand(c, generator=g)
+
+        for i in range(4):
+            for j in range(2):
+                ci, co = chans[2 * i + j]
+                p = f"backbone.{i}.{j}"
+                W[p + ".conv.weight"], W[p + ".conv.bias"] = _conv_init(g, co, ci, 3)
+                bn(p, co)
+        for head, cout in (("detector", 65), ("descriptor", 256)):
+            W[head + ".0.conv.weight"], W[head + ".0.conv.bias"] = _conv_init(g, 256, 128, 3)
+            bn(head + ".0", 256)
+            W[head + ".1.conv.weight"], W[head + ".1.conv.bias"] = _conv_init(g, cout, 256, 1)
+            bn(head + ".1", cout)
+        W["backbone.0.0.conv.weight"] = W["backbone.0.0.conv.weight"] * 8.0
+        W["detector.1.conv.weight"] = W["detector.1.conv.weight"] * 4.0
+    return W
+
+
+def make_lg_weights(seed=0, n_layers=9, dim=256, structured=True, final_gain=4.0, match_bias=0.0):
+    """Seeded LightGlue weights.
+
+    `structured=True` scales the transformer so the residual stream keeps the
+    input descriptors recognisable and sets final_proj = I, which makes the
+    assignment non-degenerate (random weights yield ~1 mutual match in 512).
+    """
+    g = torch.Generator().manual_seed(seed)
+
+    def lin(out_f, in_f, gain=1.0):
+        bound = 1.0 / math.sqrt(in_f)
+        w = (torch.rand(out_f, in_f, generator=g) * 2 - 1) * bound * gain
+        b = (torch.rand(out_f, generator=g) * 2 - 1) * bound * gain
+        return w, b
+
+    gain = 0.3 if structured else 1.0
+    W = {"posenc.Wr.weight": torch.randn(32, 2, generator=g)}
+    for i in range(n_layers):
+        for blk, names in (("self_attn", (("Wqkv", 3 * dim, dim), ("out_proj", dim, dim))),
+                           ("cross_attn", (("to_qk", dim, dim), ("to_v", dim, dim), ("to_out", dim, dim)))):
+            p = f"transformers.{i}.{blk}"
+            for n, o, ii in names:
+                W[f"{p}.{n}.weight"], W[f"{p}.{n}.bias"] = lin(o, ii, 1.0 if n in ("Wqkv", "to_qk") else gain)
+            W[p + ".ffn.0.weight"], W[p + ".ffn.0.bias"] = lin(2 * dim, 2 * dim)
+            W[p + ".ffn.1.weight"] = 0.75 + 0.5 * torch.rand(2 * dim, generator=g)
+            W[p + ".ffn.1.bias"] = 0.1 * (torch.rand(2 * dim, generator=g) - 0.5)
+            W[p + ".ffn.3.weight"], W[p + ".ffn.3.bias"] = lin(dim, 2 * dim, gain)
+        p = f"log_assignment.{i}"
+        W[p + ".matchability.weight"], W[p + ".matchability.bias"] = lin(1, dim)
+        if structured:
+            W[p + ".final_proj.weight"] = torch.eye(dim) * final_gain
+            W[p + ".matchability.bias"] = W[p + ".matchability.bias"] + match_bias
+            W[p + ".final_proj.bias"] = torch.zeros(dim)
+        else:
+            W[p + ".final_proj.weight"], W[p + ".final_proj.bias"] = lin(dim, dim)
+        if i < n_layers - 1:
+            W[f"token_confidence.{i}.token.0.weight"], W[f"token_confidence.{i}.token.0.bias"] = lin(1, dim)
+    return W

@@ -1,0 +1,285 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.npz by RUNNING THE REFERENCE ITSELF on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference's
+modules are imported unmodified; two pieces of tooling make that possible
+offline, neither of which touches arithmetic:
+  * `oracle/tools/_shim/omegaconf` -- config-merge stand-in (package not installed);
+  * `torch.hub.load_state_dict_from_url` is pointed at a local seeded
+    state_dict, because gluefactory_nonfree/superpoint.py:198-200 downloads its
+    checkpoint unconditionally and there is no network.
+Weights are the seeded sets from `oracle/sp_lg_oracle.py` (same key names as
+the reference), loaded with the reference's own `load_state_dict`.
+
+Usage:  python oracle/tools/make_goldens.py   (writes tests/golden/)
+"""
+import os
+import sys
+import warnings
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(HERE, "_shim"))
+sys.path.insert(0, "/root/reference")
+sys.path.insert(0, ROOT)
+warnings.filterwarnings("ignore")
+
+from oracle import sp_lg_oracle as O  # noqa: E402  (weight generators only)
+
+OUT = os.path.join(ROOT, "tests", "golden")
+os.makedirs(OUT, exist_ok=True)
+torch.set_num_threads(8)
+torch.set_grad_enabled(False)
+
+
+def npy(t):
+    return t.detach().cpu().numpy() if isinstance(t, torch.Tensor) else np.asarray(t)
+
+
+def save(name, **arrs):
+    path = os.path.join(OUT, name + ".npz")
+    np.savez_compressed(path, **{k: npy(v) for k, v in arrs.items()})
+    print(f"{name}: {os.path.getsize(path) / 1024:.1f} KiB, {len(arrs)} arrays")
+
+
+def load_boat():
+    from PIL import Image
+
+    out = []
+    for n in ("boat1.png", "boat2.png"):
+        im = Image.open(f"/root/reference/assets/{n}").convert("RGB")
+        out.append(np.asarray(im))
+    return out
+
+
+# ---------------------------------------------------------------- reference models
+import gluefactory_nonfree.superpoint as ref_spn  # noqa: E402
+from gluefactory.models import get_model  # noqa: E402
+from gluefactory.models.extractors import superpoint_open as ref_spo  # noqa: E402
+from gluefactory.models.two_view_pipeline import TwoViewPipeline  # noqa: E402
+
+RefLG = get_model("matchers.lightglue")
+
+
+def ref_sp_magicleap(conf, W):
+    old = torch.hub.load_state_dict_from_url
+    torch.hub.load_state_dict_from_url = lambda *a, **k: W
+    try:
+        m = ref_spn.SuperPoint(conf).eval()
+    finally:
+        torch.hub.load_state_dict_from_url = old
+    return m
+
+
+def ref_sp_open(conf, W, tmp="/tmp/_spo_seed.pth"):
+    torch.save(W, tmp)
+    return ref_spo.SuperPoint({**conf, "weights": tmp}).eval()
+
+
+def ref_lg(conf, W):
+    m = RefLG({**conf, "weights": None}).eval()
+    missing, unexpected = m.load_state_dict(W, strict=False)
+    assert not unexpected and all("loss" in k for k in missing), (missing, unexpected)
+    return m
+
+
+# ---------------------------------------------------------------- (1) nms + top-k
+def gold_nms_topk():
+    g = torch.Generator().manual_seed(11)
+    s = torch.rand(2, 64, 96, generator=g)
+    # exact ties and plateaus
+    s[0, 10:13, 20:23] = 0.99
+    s[0, 40, 50] = s[0, 40, 57] = 0.97
+    s[1] = (s[1] * 16).floor() / 16  # heavy quantisation -> many ties
+    s[1, 30:34, 60:70] = 1.0
+    arrs = {"scores": s}
+    for r in (3, 4):
+        arrs[f"nms_r{r}"] = ref_spn.simple_nms(s, r)
+        arrs[f"nms_open_r{r}"] = ref_spo.batched_nms(s, r)
+    # top-k on the NMS'd, border-masked map of image 0 (distinct values) and image 1 (ties)
+    for b in (0, 1):
+        m = arrs["nms_r3"][b].clone()
+        m[:4] = -1; m[:, :4] = -1; m[-4:] = -1; m[:, -4:] = -1
+        yx = torch.nonzero(m > 0.0)
+        v = m[yx[:, 0], yx[:, 1]]
+        arrs[f"cand_yx_{b}"] = yx
+        arrs[f"cand_v_{b}"] = v
+        for k in (16, 10 ** 6):
+            kk, vv = ref_spn.top_k_keypoints(yx, v, k)
+            arrs[f"top{k}_yx_{b}"] = kk
+            arrs[f"top{k}_v_{b}"] = vv
+    save("nms_topk", **arrs)
+
+
+# ---------------------------------------------------------------- (2,3) SuperPoint forward
+def gold_superpoint(boat):
+    img = torch.from_numpy(boat[0]).float().permute(2, 0, 1)[None] / 255.0  # (1,3,680,850)
+    gray = (img * img.new_tensor([0.299, 0.587, 0.114]).view(1, 3, 1, 1)).sum(1, keepdim=True)
+    crops = {
+        "g64x96": gray[:, :, 200:264, 300:396],
+        "rgb64x96": img[:, :, 200:264, 300:396],
+        "g68x85": gray[:, :, 100:168, 400:485],
+        "b2_g48x64": torch.cat([gray[:, :, 200:248, 300:364], gray[:, :, 300:348, 100:164]], 0),
+    }
+    W_ml = O.make_sp_weights(0, "magicleap")
+    W_op = O.make_sp_weights(0, "open")
+    arrs = {}
+    for cname, im in crops.items():
+        arrs[f"{cname}.image"] = im
+        for variant, W, mk in (("ml", W_ml, ref_sp_magicleap), ("open", W_op, ref_sp_open)):
+            for r, k, th in ((3, 24, 0.0), (4, -1, 0.005)):
+                if im.shape[0] > 1 and k < 0:
+                    continue  # ragged counts cannot be stacked by the reference
+                if im.shape[0] > 1:
+                    k = 12  # the reference only batches with force_num_keypoints (its list path calls .transpose on a list)
+                conf = {"nms_radius": r, "detection_threshold": th, "max_num_keypoints": k if (k > 0 or variant == "ml") else None,
+                        "remove_borders": 4, "dense_outputs": True, "force_num_keypoints": im.shape[0] > 1}
+                m = mk(conf, W)
+                p = m({"image": im})
+                tag = f"{cname}.{variant}.r{r}k{k}"
+                arrs[tag + ".keypoints"] = p["keypoints"]
+                arrs[tag + ".keypoint_scores"] = p["keypoint_scores"]
+                arrs[tag + ".descriptors"] = p["descriptors"]
+                arrs[f"{cname}.{variant}.dense_descriptors"] = p["dense_descriptors"]  # independent of r,k
+                if "heatmap" in p:
+                    arrs[tag + ".heatmap"] = p["heatmap"]
+    # image_size handling of the MagicLeap variant (square-padded input, config 3 style)
+    im = torch.zeros(1, 1, 64, 96)
+    im[:, :, :48, :80] = crops["g64x96"][:, :, :48, :80]
+    m = ref_sp_magicleap({"nms_radius": 3, "detection_threshold": 0.0, "max_num_keypoints": 16, "dense_outputs": True}, W_ml)
+    p = m({"image": im, "image_size": torch.tensor([[80, 48]])})
+    arrs["padded.image"] = im
+    for k in ("keypoints", "keypoint_scores", "descriptors"):
+        arrs["padded.ml.r3k16." + k] = p[k]
+    # non-legacy sampling
+    m = ref_sp_magicleap({"nms_radius": 3, "detection_threshold": 0.0, "max_num_keypoints": 24, "legacy_sampling": False}, W_ml)
+    p = m({"image": crops["g64x96"]})
+    for k in ("keypoints", "keypoint_scores", "descriptors"):
+        arrs["g64x96.ml_fixed.r3k24." + k] = p[k]
+    save("superpoint", **arrs)
+
+    # (3) sampling functions on their own
+    g = torch.Generator().manual_seed(5)
+    dense = torch.nn.functional.normalize(torch.randn(2, 256, 8, 12, generator=g), dim=1)
+    kp = torch.stack([torch.randint(0, 96, (2, 40), generator=g), torch.randint(0, 64, (2, 40), generator=g)], -1).float()
+    kp[0, 0] = torch.tensor([0.0, 0.0]); kp[0, 1] = torch.tensor([95.0, 63.0]); kp[0, 2] = torch.tensor([95.0, 0.0])
+    save(
+        "sampling",
+        dense=dense,
+        kp=kp,
+        legacy=ref_spn.sample_descriptors(kp.clone(), dense, 8),
+        fixed=ref_spn.sample_descriptors_fix_sampling(kp.clone(), dense, 8),
+        open=ref_spo.sample_descriptors(kp.clone(), dense, 8),
+    )
+
+
+# ---------------------------------------------------------------- (4) LightGlue
+def gold_lightglue():
+    arrs = {}
+    for tag, structured, M, N, seed in (("s32", True, 32, 32, 1), ("s33", True, 33, 29, 2), ("r32", False, 32, 32, 3), ("s64", True, 64, 48, 4)):
+        g = torch.Generator().manual_seed(100 + seed)
+        W = O.make_lg_weights(seed, structured=structured)
+        B = 2
+        size0 = torch.tensor([[640.0, 480.0]] * B)
+        size1 = torch.tensor([[600.0, 480.0]] * B)
+        k0 = torch.rand(B, M, 2, generator=g) * size0[:, None] * 0.98 + 0.5
+        d0 = torch.nn.functional.normalize(torch.randn(B, M, 256, generator=g), dim=-1)
+        # image 1 = permuted, perturbed subset of image 0 so real matches exist
+        perm = torch.stack([torch.randperm(M, generator=g)[:N] for _ in range(B)])
+        k1 = torch.gather(k0, 1, perm[..., None].expand(-1, -1, 2)) * 0.9 + 3.0 * torch.randn(B, N, 2, generator=g)
+        d1 = torch.gather(d0, 1, perm[..., None].expand(-1, -1, 256)) + 0.05 * torch.randn(B, N, 256, generator=g)
+        d1 = torch.nn.functional.normalize(d1, dim=-1)
+        data = {"keypoints0": k0, "keypoints1": k1, "descriptors0": d0, "descriptors1": d1,
+                "view0": {"image_size": size0}, "view1": {"image_size": size1}}
+        for k, v in (("keypoints0", k0), ("keypoints1", k1), ("descriptors0", d0), ("descriptors1", d1), ("size0", size0), ("size1", size1)):
+            arrs[f"{tag}.{k}"] = v
+        for th in (0.0, 0.1):
+            m = ref_lg({"filter_threshold": th}, W)
+            hooks = {}
+            if th == 0.0:
+                def mk(i):
+                    def hook(mod, inp, out):
+                        hooks[i] = out
+                    return hook
+                hs = [m.transformers[i].register_forward_hook(mk(i)) for i in (0, 8)]
+                hs.append(m.transformers[0].self_attn.register_forward_hook(lambda mod, inp, out: hooks.setdefault("self0", []).append(out)))
+            p = m(data)
+            if th == 0.0:
+                for h in hs:
+                    h.remove()
+                for i in (0, 8):
+                    arrs[f"{tag}.layer{i}.desc0"], arrs[f"{tag}.layer{i}.desc1"] = hooks[i]
+                arrs[f"{tag}.self0.desc0"], arrs[f"{tag}.self0.desc1"] = hooks["self0"]
+                arrs[f"{tag}.log_assignment"] = p["log_assignment"]
+                inner = p["log_assignment"][:, :-1, :-1]
+                arrs[f"{tag}.argmax0"] = inner.max(2).indices
+                arrs[f"{tag}.argmax1"] = inner.max(1).indices
+                arrs[f"{tag}.ref_descriptors0"] = p["ref_descriptors0"]
+                arrs[f"{tag}.prune0"] = p["prune0"]
+                # positional encoding on its own
+                from gluefactory.models.matchers.lightglue import normalize_keypoints
+                arrs[f"{tag}.kn0"] = normalize_keypoints(k0, size0)
+                arrs[f"{tag}.enc0"] = m.posenc(normalize_keypoints(k0, size0))
+            for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+                arrs[f"{tag}.th{th}.{k}"] = p[k]
+    save("lightglue", **arrs)
+
+
+# ---------------------------------------------------------------- (5) two-view pipeline on the boat pair
+def gold_two_view(boat):
+    g0 = np.round(boat[0].astype(np.float32) @ np.array([0.299, 0.587, 0.114], np.float32)).astype(np.uint8)
+    g1 = np.round(boat[1].astype(np.float32) @ np.array([0.299, 0.587, 0.114], np.float32)).astype(np.uint8)
+    arrs = {"gray0": g0, "gray1": g1}
+    im0 = torch.from_numpy(g0).float()[None, None] / 255.0
+    im1 = torch.from_numpy(g1).float()[None, None] / 255.0
+    W_lg = O.make_lg_weights(7, structured=True, final_gain=8.0, match_bias=2.0)
+    for variant in ("open", "ml"):
+        W_sp = O.make_sp_weights(0, "open" if variant == "open" else "magicleap")
+        if variant == "open":
+            torch.save(W_sp, "/tmp/_spo_seed.pth")
+            ext = {"name": "extractors.superpoint_open", "max_num_keypoints": 512, "nms_radius": 3, "detection_threshold": 0.0,
+                   "weights": "/tmp/_spo_seed.pth"}
+        else:
+            ext = {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": 512, "nms_radius": 3, "detection_threshold": 0.0}
+        conf = {"extractor": ext, "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "weights": None}}
+        old = torch.hub.load_state_dict_from_url
+        torch.hub.load_state_dict_from_url = lambda *a, **k: W_sp
+        try:
+            pipe = TwoViewPipeline(conf).eval()
+        finally:
+            torch.hub.load_state_dict_from_url = old
+        pipe.matcher.load_state_dict(W_lg, strict=False)
+        size = torch.tensor([[im0.shape[-1], im0.shape[-2]]]).float()
+        data = {"view0": {"image": im0, "image_size": size}, "view1": {"image": im1, "image_size": size}}
+        p = pipe(data)
+        arrs[f"{variant}.keys"] = np.array(sorted(p.keys()))
+        for k in ("keypoints0", "keypoints1", "keypoint_scores0", "keypoint_scores1", "matches0", "matches1",
+                  "matching_scores0", "matching_scores1", "prune0"):
+            arrs[f"{variant}.{k}"] = p[k]
+        arrs[f"{variant}.descriptors0_rows"] = p["descriptors0"][0, ::8]
+        arrs[f"{variant}.descriptors1_rows"] = p["descriptors1"][0, ::8]
+        arrs[f"{variant}.desc0_sum"] = p["descriptors0"].double().sum(-1)
+        arrs[f"{variant}.log_assignment_rowsum"] = p["log_assignment"].double().sum(-1)
+        arrs[f"{variant}.log_assignment_diag"] = p["log_assignment"][0, ::16, ::16]
+        print(variant, "matches:", int((p["matches0"] > -1).sum()), "of", p["matches0"].shape[1])
+        # shifted self-pair: view1 = view0 translated by (24,16) px -> SuperPoint is equivariant to
+        # multiples of 8 px, so genuine correspondences exist even with seeded weights
+        a = im0[:, :, 0:640, 0:800].contiguous()
+        b = im0[:, :, 16:656, 24:824].contiguous()
+        size = torch.tensor([[800.0, 640.0]])
+        p = pipe({"view0": {"image": a, "image_size": size}, "view1": {"image": b, "image_size": size}})
+        for k in ("keypoints0", "keypoints1", "matches0", "matches1", "matching_scores0", "matching_scores1"):
+            arrs[f"{variant}.shift.{k}"] = p[k]
+        print(variant, "shifted-pair matches:", int((p["matches0"] > -1).sum()), "of", p["matches0"].shape[1])
+    save("two_view_boat", **arrs)
+
+
+if __name__ == "__main__":
+    boat = load_boat()
+    gold_nms_topk()
+    gold_superpoint(boat)
+    gold_lightglue()
+    gold_two_view(boat)
