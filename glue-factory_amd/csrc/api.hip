@@ -1,0 +1,761 @@
+// C ABI of libmatchglue (include/matchglue.h): handle, weight upload / re-tiling, workspace, and
+// the launch sequences of the SuperPoint and LightGlue forward passes.
+#include "../../include/matchglue.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "kernels.h"
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+
+#define HIPCHK(expr)                                                                                     \
+    do {                                                                                                 \
+        hipError_t e_ = (expr);                                                                          \
+        if (e_ != hipSuccess) return fail(MG_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+struct HostTensor {
+    std::vector<float> data;
+    std::vector<int64_t> shape;
+    int64_t numel() const {
+        int64_t n = 1;
+        for (auto s : shape) n *= s;
+        return n;
+    }
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t bytes = 0;
+    int ensure(size_t need) {
+        if (need <= bytes) return 0;
+        if (p) {
+            if (hipDeviceSynchronize() != hipSuccess) return -1;
+            hipFree(p);
+            p = nullptr;
+            bytes = 0;
+        }
+        size_t alloc = need + (need >> 3) + 256;
+        if (hipMalloc(&p, alloc) != hipSuccess) {
+            p = nullptr;
+            return -1;
+        }
+        bytes = alloc;
+        return 0;
+    }
+    float* f() const { return static_cast<float*>(p); }
+    void release() {
+        if (p) hipFree(p);
+        p = nullptr;
+        bytes = 0;
+    }
+};
+
+struct ConvLayer {
+    int Cin = 0, Cout = 0, CoutPad = 0;
+    float *W = nullptr, *bias = nullptr, *ps = nullptr, *pt = nullptr;
+};
+struct LinLayer {
+    int N = 0, K = 0, Npad = 0;
+    float *W = nullptr, *bias = nullptr, *ps = nullptr, *pt = nullptr;
+};
+struct LgBlock {
+    LinLayer proj;  // self: Wqkv (q|k|v rows), cross: [to_qk ; to_v]
+    LinLayer out;   // out_proj / to_out
+    LinLayer ffn0, ffn3;
+    float *ln_g = nullptr, *ln_b = nullptr;
+};
+
+struct ProfEntry {
+    std::string name;
+    hipEvent_t a, b;
+};
+
+}  // namespace
+
+struct mg_context {
+    int device = 0;
+    std::map<std::string, HostTensor> raw[2];
+    std::vector<void*> owned;  // device allocations of prepared weights
+
+    // SuperPoint
+    int sp_variant = -1;
+    float *c1a_w = nullptr, *c1a_b = nullptr, *c1a_ps = nullptr, *c1a_pt = nullptr;
+    ConvLayer conv[9];  // conv1b,2a,2b,3a,3b,4a,4b,Pa,Da
+    LinLayer convPb, convDb;
+    // LightGlue
+    int lg_layers = -1;
+    std::vector<LgBlock> lg_self, lg_cross;
+    LinLayer final_proj;
+    float* match_w = nullptr;
+    float match_b = 0.f;
+    float* Wr = nullptr;
+
+    // workspace
+    std::map<std::string, DevBuf> ws;
+    std::map<std::string, DevBuf> taps;
+    std::map<std::string, size_t> tap_count;
+
+    bool profile = false;
+    std::vector<ProfEntry> prof;
+    std::vector<hipEvent_t> event_pool;
+    size_t event_used = 0;
+
+    float* buf(const std::string& name, size_t floats) {
+        DevBuf& b = ws[name];
+        if (b.ensure(floats * sizeof(float)) != 0) return nullptr;
+        return b.f();
+    }
+    hipEvent_t next_event() {
+        if (event_used == event_pool.size()) {
+            hipEvent_t e;
+            hipEventCreate(&e);
+            event_pool.push_back(e);
+        }
+        return event_pool[event_used++];
+    }
+};
+
+namespace {
+
+struct ProfScope {
+    mg_context* h;
+    hipStream_t s;
+    size_t idx = 0;
+    bool on;
+    ProfScope(mg_context* h_, hipStream_t s_, const char* name) : h(h_), s(s_), on(h_->profile) {
+        if (!on) return;
+        ProfEntry e;
+        e.name = name;
+        e.a = h->next_event();
+        e.b = h->next_event();
+        hipEventRecord(e.a, s);
+        idx = h->prof.size();
+        h->prof.push_back(e);
+    }
+    ~ProfScope() {
+        if (on) hipEventRecord(h->prof[idx].b, s);
+    }
+};
+
+int upload(mg_context* h, const std::vector<float>& v, float** out) {
+    void* p = nullptr;
+    HIPCHK(hipMalloc(&p, v.size() * sizeof(float)));
+    HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
+    h->owned.push_back(p);
+    *out = static_cast<float*>(p);
+    return 0;
+}
+
+const HostTensor* find(mg_context* h, int which, const std::string& key) {
+    auto it = h->raw[which].find(key);
+    return it == h->raw[which].end() ? nullptr : &it->second;
+}
+
+int need(mg_context* h, int which, const std::string& key, std::initializer_list<int64_t> shape, const HostTensor** out) {
+    const HostTensor* t = find(h, which, key);
+    if (!t) return fail(MG_ERR_WEIGHTS, "missing weight tensor '" + key + "'");
+    std::vector<int64_t> want(shape);
+    int64_t n = 1;
+    for (auto s : want) n *= s;
+    if (t->numel() != n) return fail(MG_ERR_WEIGHTS, "weight tensor '" + key + "' has the wrong number of elements");
+    *out = t;
+    return 0;
+}
+
+// OIHW 3x3 -> [Cin/8][9][CoutPad][8]
+int prep_conv3(mg_context* h, int which, const std::string& wkey, const std::string& bkey, int Cin, int Cout, ConvLayer* L) {
+    const HostTensor *w, *b;
+    if (int rc = need(h, which, wkey, {Cout, Cin, 3, 3}, &w)) return rc;
+    if (int rc = need(h, which, bkey, {Cout}, &b)) return rc;
+    L->Cin = Cin;
+    L->Cout = Cout;
+    L->CoutPad = (Cout + 63) / 64 * 64;
+    std::vector<float> t((size_t)(Cin / 8) * 9 * L->CoutPad * 8, 0.f);
+    for (int n = 0; n < Cout; ++n)
+        for (int c = 0; c < Cin; ++c)
+            for (int tap = 0; tap < 9; ++tap)
+                t[(((size_t)(c >> 3) * 9 + tap) * L->CoutPad + n) * 8 + (c & 7)] = w->data[((size_t)n * Cin + c) * 9 + tap];
+    if (int rc = upload(h, t, &L->W)) return rc;
+    return upload(h, b->data, &L->bias);
+}
+
+// [N][K] -> [K/8][Npad][8]; `perm` optionally maps new row -> old row
+int prep_linear_rows(mg_context* h, const std::vector<const float*>& rows, const std::vector<float>& bias, int K, LinLayer* L) {
+    const int N = (int)rows.size();
+    L->N = N;
+    L->K = K;
+    L->Npad = (N + 127) / 128 * 128;
+    std::vector<float> t((size_t)(K / 8) * L->Npad * 8, 0.f);
+    for (int n = 0; n < N; ++n)
+        for (int k = 0; k < K; ++k) t[((size_t)(k >> 3) * L->Npad + n) * 8 + (k & 7)] = rows[n][k];
+    if (int rc = upload(h, t, &L->W)) return rc;
+    if (!bias.empty()) return upload(h, bias, &L->bias);
+    return 0;
+}
+
+int prep_linear(mg_context* h, int which, const std::string& prefix, int N, int K, LinLayer* L) {
+    const HostTensor *w, *b;
+    if (int rc = need(h, which, prefix + ".weight", {N, K}, &w)) return rc;
+    if (int rc = need(h, which, prefix + ".bias", {N}, &b)) return rc;
+    std::vector<const float*> rows(N);
+    for (int n = 0; n < N; ++n) rows[n] = w->data.data() + (size_t)n * K;
+    return prep_linear_rows(h, rows, b->data, K, L);
+}
+
+// BatchNorm (eval) -> per-channel affine after the activation
+int prep_bn(mg_context* h, const std::string& prefix, int C, float** ps, float** pt) {
+    const HostTensor *g, *b, *m, *v;
+    if (int rc = need(h, 0, prefix + ".weight", {C}, &g)) return rc;
+    if (int rc = need(h, 0, prefix + ".bias", {C}, &b)) return rc;
+    if (int rc = need(h, 0, prefix + ".running_mean", {C}, &m)) return rc;
+    if (int rc = need(h, 0, prefix + ".running_var", {C}, &v)) return rc;
+    std::vector<float> s(C), t(C);
+    for (int c = 0; c < C; ++c) {
+        const float invstd = 1.0f / std::sqrt(v->data[c] + 1e-3f);
+        const float alpha = invstd * g->data[c];
+        s[c] = alpha;
+        t[c] = b->data[c] - m->data[c] * alpha;
+    }
+    if (int rc = upload(h, s, ps)) return rc;
+    return upload(h, t, pt);
+}
+
+int prepare_sp(mg_context* h, int variant) {
+    if (h->sp_variant == variant) return 0;
+    const int cin[9] = {64, 64, 64, 64, 128, 128, 128, 128, 128};
+    const int cout[9] = {64, 64, 64, 128, 128, 128, 128, 256, 256};
+    if (variant == MG_SP_MAGICLEAP) {
+        const char* names[9] = {"conv1b", "conv2a", "conv2b", "conv3a", "conv3b", "conv4a", "conv4b", "convPa", "convDa"};
+        const HostTensor *w, *b;
+        if (int rc = need(h, 0, "conv1a.weight", {64, 1, 3, 3}, &w)) return rc;
+        if (int rc = need(h, 0, "conv1a.bias", {64}, &b)) return rc;
+        if (int rc = upload(h, w->data, &h->c1a_w)) return rc;
+        if (int rc = upload(h, b->data, &h->c1a_b)) return rc;
+        h->c1a_ps = h->c1a_pt = nullptr;
+        for (int i = 0; i < 9; ++i) {
+            h->conv[i] = ConvLayer();
+            if (int rc = prep_conv3(h, 0, std::string(names[i]) + ".weight", std::string(names[i]) + ".bias", cin[i], cout[i], &h->conv[i])) return rc;
+        }
+        h->convPb = LinLayer();
+        h->convDb = LinLayer();
+        if (int rc = prep_linear(h, 0, "convPb", 65, 256, &h->convPb)) return rc;
+        if (int rc = prep_linear(h, 0, "convDb", 256, 256, &h->convDb)) return rc;
+    } else if (variant == MG_SP_OPEN) {
+        const char* names[9] = {"backbone.0.1", "backbone.1.0", "backbone.1.1", "backbone.2.0", "backbone.2.1",
+                                "backbone.3.0", "backbone.3.1", "detector.0", "descriptor.0"};
+        const HostTensor *w, *b;
+        if (int rc = need(h, 0, "backbone.0.0.conv.weight", {64, 1, 3, 3}, &w)) return rc;
+        if (int rc = need(h, 0, "backbone.0.0.conv.bias", {64}, &b)) return rc;
+        if (int rc = upload(h, w->data, &h->c1a_w)) return rc;
+        if (int rc = upload(h, b->data, &h->c1a_b)) return rc;
+        if (int rc = prep_bn(h, "backbone.0.0.bn", 64, &h->c1a_ps, &h->c1a_pt)) return rc;
+        for (int i = 0; i < 9; ++i) {
+            h->conv[i] = ConvLayer();
+            const std::string n = names[i];
+            if (int rc = prep_conv3(h, 0, n + ".conv.weight", n + ".conv.bias", cin[i], cout[i], &h->conv[i])) return rc;
+            if (int rc = prep_bn(h, n + ".bn", cout[i], &h->conv[i].ps, &h->conv[i].pt)) return rc;
+        }
+        h->convPb = LinLayer();
+        h->convDb = LinLayer();
+        if (int rc = prep_linear(h, 0, "detector.1.conv", 65, 256, &h->convPb)) return rc;
+        if (int rc = prep_bn(h, "detector.1.bn", 65, &h->convPb.ps, &h->convPb.pt)) return rc;
+        if (int rc = prep_linear(h, 0, "descriptor.1.conv", 256, 256, &h->convDb)) return rc;
+        if (int rc = prep_bn(h, "descriptor.1.bn", 256, &h->convDb.ps, &h->convDb.pt)) return rc;
+    } else {
+        return fail(MG_ERR_ARG, "unknown SuperPoint variant");
+    }
+    h->sp_variant = variant;
+    return 0;
+}
+
+int prep_ffn(mg_context* h, const std::string& p, LgBlock* blk) {
+    if (int rc = prep_linear(h, 1, p + ".ffn.0", 512, 512, &blk->ffn0)) return rc;
+    if (int rc = prep_linear(h, 1, p + ".ffn.3", 256, 512, &blk->ffn3)) return rc;
+    const HostTensor *g, *b;
+    if (int rc = need(h, 1, p + ".ffn.1.weight", {512}, &g)) return rc;
+    if (int rc = need(h, 1, p + ".ffn.1.bias", {512}, &b)) return rc;
+    if (int rc = upload(h, g->data, &blk->ln_g)) return rc;
+    return upload(h, b->data, &blk->ln_b);
+}
+
+int prepare_lg(mg_context* h, int n_layers) {
+    if (h->lg_layers == n_layers) return 0;
+    h->lg_self.assign(n_layers, LgBlock());
+    h->lg_cross.assign(n_layers, LgBlock());
+    for (int i = 0; i < n_layers; ++i) {
+        const std::string ps = "transformers." + std::to_string(i) + ".self_attn";
+        const std::string pc = "transformers." + std::to_string(i) + ".cross_attn";
+        // Wqkv: reference feature f = head*192 + dim*3 + {q,k,v} (lightglue.py:151-152); re-ordered here to
+        // [q | k | v] x [head][dim] so rotary pairs are adjacent columns and attention reads 64-wide head slices.
+        const HostTensor *w, *b;
+        if (int rc = need(h, 1, ps + ".Wqkv.weight", {768, 256}, &w)) return rc;
+        if (int rc = need(h, 1, ps + ".Wqkv.bias", {768}, &b)) return rc;
+        std::vector<const float*> rows(768);
+        std::vector<float> bias(768);
+        for (int which = 0; which < 3; ++which)
+            for (int hd = 0; hd < 4; ++hd)
+                for (int d = 0; d < 64; ++d) {
+                    const int nn = which * 256 + hd * 64 + d, old = hd * 192 + d * 3 + which;
+                    rows[nn] = w->data.data() + (size_t)old * 256;
+                    bias[nn] = b->data[old];
+                }
+        if (int rc = prep_linear_rows(h, rows, bias, 256, &h->lg_self[i].proj)) return rc;
+        if (int rc = prep_linear(h, 1, ps + ".out_proj", 256, 256, &h->lg_self[i].out)) return rc;
+        if (int rc = prep_ffn(h, ps, &h->lg_self[i])) return rc;
+        // cross: one GEMM for [to_qk ; to_v]
+        const HostTensor *wq, *bq, *wv, *bv;
+        if (int rc = need(h, 1, pc + ".to_qk.weight", {256, 256}, &wq)) return rc;
+        if (int rc = need(h, 1, pc + ".to_qk.bias", {256}, &bq)) return rc;
+        if (int rc = need(h, 1, pc + ".to_v.weight", {256, 256}, &wv)) return rc;
+        if (int rc = need(h, 1, pc + ".to_v.bias", {256}, &bv)) return rc;
+        std::vector<const float*> rows2(512);
+        std::vector<float> bias2(512);
+        for (int n = 0; n < 256; ++n) {
+            rows2[n] = wq->data.data() + (size_t)n * 256;
+            bias2[n] = bq->data[n];
+            rows2[256 + n] = wv->data.data() + (size_t)n * 256;
+            bias2[256 + n] = bv->data[n];
+        }
+        if (int rc = prep_linear_rows(h, rows2, bias2, 256, &h->lg_cross[i].proj)) return rc;
+        if (int rc = prep_linear(h, 1, pc + ".to_out", 256, 256, &h->lg_cross[i].out)) return rc;
+        if (int rc = prep_ffn(h, pc, &h->lg_cross[i])) return rc;
+    }
+    const std::string pa = "log_assignment." + std::to_string(n_layers - 1);
+    if (int rc = prep_linear(h, 1, pa + ".final_proj", 256, 256, &h->final_proj)) return rc;
+    const HostTensor *mw, *mb, *wr;
+    if (int rc = need(h, 1, pa + ".matchability.weight", {1, 256}, &mw)) return rc;
+    if (int rc = need(h, 1, pa + ".matchability.bias", {1}, &mb)) return rc;
+    if (int rc = upload(h, mw->data, &h->match_w)) return rc;
+    h->match_b = mb->data[0];
+    if (int rc = need(h, 1, "posenc.Wr.weight", {32, 2}, &wr)) return rc;
+    if (int rc = upload(h, wr->data, &h->Wr)) return rc;
+    h->lg_layers = n_layers;
+    return 0;
+}
+
+GemmArgs lin_args(const LinLayer& L, const float* A, int lda, int M, float* C, int ldc) {
+    GemmArgs g;
+    g.A0 = A;
+    g.lda0 = lda;
+    g.ksplit = L.K;
+    g.W = L.W;
+    g.Npad = L.Npad;
+    g.bias = L.bias;
+    g.post_scale = L.ps;
+    g.post_shift = L.pt;
+    g.C = C;
+    g.ldc = ldc;
+    g.M = M;
+    g.N = L.N;
+    g.K = L.K;
+    return g;
+}
+
+int tap_copy(mg_context* h, const std::string& name, const float* src, size_t count, hipStream_t s) {
+    auto it = h->taps.find(name);
+    if (it == h->taps.end()) return 0;
+    if (it->second.ensure(count * sizeof(float)) != 0) return fail(MG_ERR_HIP, "tap allocation failed");
+    HIPCHK(hipMemcpyAsync(it->second.p, src, count * sizeof(float), hipMemcpyDeviceToDevice, s));
+    h->tap_count[name] = count;
+    return 0;
+}
+
+int run_detect(mg_context* h, const mg_sp_conf* conf, const float* heat, int B, int Hs, int Ws, const float* image_size,
+               float* keypoints, float* scores, int32_t* num_valid, float* nms_out, hipStream_t s) {
+    if (conf->nms_radius < 0 || conf->nms_radius > 4) return fail(MG_ERR_ARG, "nms_radius must be in [0,4]");
+    if (conf->max_num_keypoints < 1 || conf->max_num_keypoints > 4096) return fail(MG_ERR_ARG, "max_num_keypoints must be in [1,4096]");
+    DetectArgs d;
+    d.heat = heat;
+    d.B = B;
+    d.Hs = Hs;
+    d.Ws = Ws;
+    d.radius = conf->nms_radius;
+    d.border = conf->remove_borders;
+    d.K = conf->max_num_keypoints;
+    d.threshold = conf->detection_threshold;
+    d.image_size = (conf->variant == MG_SP_MAGICLEAP) ? image_size : nullptr;
+    d.cand = reinterpret_cast<unsigned long long*>(h->buf("sp.cand", (size_t)B * Hs * Ws * 2));
+    d.counts = reinterpret_cast<int*>(h->buf("sp.counts", (size_t)B));
+    if (!d.cand || !d.counts) return fail(MG_ERR_HIP, "workspace allocation failed");
+    d.nms_out = nms_out;
+    d.keypoints = keypoints;
+    d.scores = scores;
+    d.num_valid = num_valid;
+    ProfScope ps(h, s, "sp.detect");
+    launch_detect(d, s);
+    return 0;
+}
+
+}  // namespace
+
+// ================================================================================================
+extern "C" {
+
+int mg_abi_version(void) { return 1; }
+
+const char* mg_last_error(void) { return g_err.c_str(); }
+
+int mg_create(int device, mg_handle* out) {
+    if (!out) return fail(MG_ERR_ARG, "out is NULL");
+    int n = 0;
+    HIPCHK(hipGetDeviceCount(&n));
+    if (device < 0 || device >= n) return fail(MG_ERR_ARG, "no such HIP device");
+    HIPCHK(hipSetDevice(device));
+    mg_context* h = new mg_context();
+    h->device = device;
+    *out = h;
+    return 0;
+}
+
+int mg_destroy(mg_handle h) {
+    if (!h) return 0;
+    hipSetDevice(h->device);
+    hipDeviceSynchronize();
+    for (void* p : h->owned) hipFree(p);
+    for (auto& kv : h->ws) kv.second.release();
+    for (auto& kv : h->taps) kv.second.release();
+    for (auto e : h->event_pool) hipEventDestroy(e);
+    delete h;
+    return 0;
+}
+
+int mg_set_weight(mg_handle h, int which, const char* key, const float* data, const int64_t* shape, int ndim) {
+    if (!h || !key || !data || which < 0 || which > 1 || ndim < 0 || (ndim > 0 && !shape)) return fail(MG_ERR_ARG, "bad argument");
+    HostTensor t;
+    t.shape.assign(shape, shape + ndim);
+    t.data.assign(data, data + t.numel());
+    h->raw[which][key] = std::move(t);
+    if (which == 0) h->sp_variant = -1; else h->lg_layers = -1;  // re-tile on next use
+    return 0;
+}
+
+int mg_weights_ready(mg_handle h, int which, int variant_or_layers) {
+    if (!h) return fail(MG_ERR_ARG, "handle is NULL");
+    HIPCHK(hipSetDevice(h->device));
+    if (which == 0) return prepare_sp(h, variant_or_layers);
+    return prepare_lg(h, variant_or_layers > 0 ? variant_or_layers : 9);
+}
+
+int mg_debug_request(mg_handle h, const char* tap) {
+    if (!h || !tap) return fail(MG_ERR_ARG, "bad argument");
+    h->taps[tap];
+    return 0;
+}
+
+int mg_debug_read(mg_handle h, const char* tap, float* dst, size_t capacity, size_t* count, void* stream) {
+    if (!h || !tap || !dst) return fail(MG_ERR_ARG, "bad argument");
+    auto it = h->tap_count.find(tap);
+    if (it == h->tap_count.end()) return fail(MG_ERR_STATE, std::string("tap '") + tap + "' was not captured");
+    if (it->second > capacity) return fail(MG_ERR_ARG, "destination too small");
+    HIPCHK(hipMemcpyAsync(dst, h->taps[tap].p, it->second * sizeof(float), hipMemcpyDeviceToDevice, static_cast<hipStream_t>(stream)));
+    if (count) *count = it->second;
+    return 0;
+}
+
+int mg_profile_enable(mg_handle h, int on) {
+    if (!h) return fail(MG_ERR_ARG, "handle is NULL");
+    h->profile = on != 0;
+    h->prof.clear();
+    h->event_used = 0;
+    return 0;
+}
+
+int mg_profile_read(mg_handle h, char (*names)[48], float* ms, int cap) {
+    if (!h) return fail(MG_ERR_ARG, "handle is NULL");
+    int n = 0;
+    for (auto& e : h->prof) {
+        if (n >= cap) break;
+        HIPCHK(hipEventSynchronize(e.b));
+        float t = 0.f;
+        HIPCHK(hipEventElapsedTime(&t, e.a, e.b));
+        std::snprintf(names[n], 48, "%s", e.name.c_str());
+        ms[n] = t;
+        ++n;
+    }
+    const int total = (int)h->prof.size();
+    h->prof.clear();
+    h->event_used = 0;
+    return total < cap ? total : n;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mg_sp_detect(mg_handle h, const mg_sp_conf* conf, const float* heatmap, int B, int Hs, int Ws, const float* image_size,
+                 float* keypoints, float* scores, int32_t* num_valid, float* nms_out, void* stream) {
+    if (!h || !conf || !heatmap || !keypoints || !scores || !num_valid || B < 1 || Hs < 1 || Ws < 1) return fail(MG_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    if (int rc = run_detect(h, conf, heatmap, B, Hs, Ws, image_size, keypoints, scores, num_valid, nms_out, static_cast<hipStream_t>(stream))) return rc;
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int mg_sp_sample(mg_handle h, const mg_sp_conf* conf, const float* keypoints, const float* dense_nchw, int B, int K, int Hc, int Wc,
+                 float* descriptors, void* stream) {
+    if (!h || !conf || !keypoints || !dense_nchw || !descriptors || B < 1 || K < 1) return fail(MG_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    float* nhwc = h->buf("sp.sample_nhwc", (size_t)B * Hc * Wc * 256);
+    if (!nhwc) return fail(MG_ERR_HIP, "workspace allocation failed");
+    launch_nchw_to_nhwc(dense_nchw, nhwc, B, Hc * Wc, 256, s);
+    SampleArgs a;
+    a.keypoints = keypoints;
+    a.dense = nhwc;
+    a.B = B;
+    a.K = K;
+    a.hc = Hc;
+    a.wc = Wc;
+    a.mode = conf->sampling;
+    a.desc = descriptors;
+    launch_sample(a, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B, int C, int H, int W, const float* image_size,
+                  float* keypoints, float* scores, float* descriptors, int32_t* num_valid, float* heatmap, float* dense_desc,
+                  void* stream) {
+    if (!h || !conf || !image || !keypoints || !scores || !descriptors || !num_valid) return fail(MG_ERR_ARG, "NULL argument");
+    if (B < 1 || (C != 1 && C != 3) || H < 16 || W < 16) return fail(MG_ERR_ARG, "unsupported image shape");
+    HIPCHK(hipSetDevice(h->device));
+    if (int rc = prepare_sp(h, conf->variant)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, hc = H4 / 2, wc = W4 / 2;
+    const size_t n1 = (size_t)B * H * W, n2 = (size_t)B * H2 * W2, n4 = (size_t)B * H4 * W4, n8 = (size_t)B * hc * wc;
+    float* a1 = h->buf("sp.a1", n1 * 64);
+    float* p1 = h->buf("sp.p1", n2 * 64);
+    float* a2 = h->buf("sp.a2", n2 * 64);
+    float* p2 = h->buf("sp.p2", n4 * 64);
+    float* a3 = h->buf("sp.a3", n4 * 128);
+    float* p3 = h->buf("sp.p3", n8 * 128);
+    float* a4 = h->buf("sp.a4", n8 * 128);
+    float* f4 = h->buf("sp.f4", n8 * 128);
+    float* cP = h->buf("sp.cP", n8 * 256);
+    float* cD = h->buf("sp.cD", n8 * 256);
+    float* lg = h->buf("sp.logits", n8 * 65);
+    float* dd = h->buf("sp.dense", n8 * 256);
+    float* heat = h->buf("sp.heat", n8 * 64);
+    if (!a1 || !p1 || !a2 || !p2 || !a3 || !p3 || !a4 || !f4 || !cP || !cD || !lg || !dd || !heat) return fail(MG_ERR_HIP, "workspace allocation failed");
+
+    {
+        ProfScope ps(h, s, "sp.conv1a");
+        Conv1aArgs a;
+        a.image = image; a.B = B; a.C = C; a.H = H; a.W = W;
+        a.w = h->c1a_w; a.bias = h->c1a_b; a.post_scale = h->c1a_ps; a.post_shift = h->c1a_pt; a.out = a1;
+        launch_conv1a(a, s);
+    }
+    struct Step { const char* name; int layer; const float* in; float* out; int Hh, Ww, pool; };
+    const Step steps[9] = {
+        {"sp.conv1b", 0, a1, p1, H, W, 1},   {"sp.conv2a", 1, p1, a2, H2, W2, 0}, {"sp.conv2b", 2, a2, p2, H2, W2, 1},
+        {"sp.conv3a", 3, p2, a3, H4, W4, 0}, {"sp.conv3b", 4, a3, p3, H4, W4, 1}, {"sp.conv4a", 5, p3, a4, hc, wc, 0},
+        {"sp.conv4b", 6, a4, f4, hc, wc, 0}, {"sp.convPa", 7, f4, cP, hc, wc, 0}, {"sp.convDa", 8, f4, cD, hc, wc, 0}};
+    for (const Step& st : steps) {
+        ProfScope ps(h, s, st.name);
+        const ConvLayer& L = h->conv[st.layer];
+        ConvArgs a;
+        a.in = st.in; a.Wt = L.W; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
+        a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = st.pool; a.relu = 1;
+        launch_conv3x3(a, s);
+    }
+    {
+        ProfScope ps(h, s, "sp.convPb");
+        GemmArgs g = lin_args(h->convPb, cP, 256, (int)n8, lg, 65);
+        launch_gemm(g, s);
+    }
+    {
+        ProfScope ps(h, s, "sp.softmax_d2s");
+        launch_softmax_d2s(lg, 65, B, hc, wc, heat, s);
+    }
+    {
+        ProfScope ps(h, s, "sp.convDb");
+        GemmArgs g = lin_args(h->convDb, cD, 256, (int)n8, dd, 256);
+        launch_gemm(g, s);
+    }
+    {
+        ProfScope ps(h, s, "sp.l2norm");
+        launch_l2norm_rows(dd, (long long)n8, 256, s);
+    }
+    if (int rc = run_detect(h, conf, heat, B, hc * 8, wc * 8, image_size, keypoints, scores, num_valid, nullptr, s)) return rc;
+    {
+        ProfScope ps(h, s, "sp.sample");
+        SampleArgs a;
+        a.keypoints = keypoints; a.dense = dd; a.B = B; a.K = conf->max_num_keypoints; a.hc = hc; a.wc = wc;
+        a.mode = conf->sampling; a.desc = descriptors;
+        launch_sample(a, s);
+    }
+    if (heatmap) HIPCHK(hipMemcpyAsync(heatmap, heat, n8 * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (dense_desc) launch_nhwc_to_nchw(dd, dense_desc, B, hc * wc, 256, s);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
+                  const float* size0, const float* size1, int B, int M, int N, int64_t* matches0, int64_t* matches1, float* mscores0,
+                  float* mscores1, float* log_assignment, float* ref_desc0, float* ref_desc1, void* stream) {
+    if (!h || !conf || !kpts0 || !kpts1 || !desc0 || !desc1 || !matches0 || !matches1 || !mscores0 || !mscores1) return fail(MG_ERR_ARG, "NULL argument");
+    if (B < 1 || M < 1 || N < 1) return fail(MG_ERR_ARG, "empty input");
+    if (conf->num_heads != 4) return fail(MG_ERR_ARG, "num_heads must be 4 (descriptor_dim 256, head_dim 64)");
+    if (conf->n_layers < 1) return fail(MG_ERR_ARG, "n_layers must be >= 1");
+    HIPCHK(hipSetDevice(h->device));
+    if (int rc = prepare_lg(h, conf->n_layers)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+
+    const size_t T0 = (size_t)B * M, T1 = (size_t)B * N, T = T0 + T1;
+    float* X = h->buf("lg.x", T * 256);
+    float* QKV = h->buf("lg.qkv", T * 768);
+    float* CTX = h->buf("lg.ctx", T * 256);
+    float* MSG = h->buf("lg.msg", T * 256);
+    float* HID = h->buf("lg.hid", T * 512);
+    float* ENC = h->buf("lg.enc", T * 64);
+    float* SIM = h->buf("lg.sim", (size_t)B * M * N);
+    float* Z = h->buf("lg.z", T);
+    float* ST = h->buf("lg.stats", 6 * T + 16);
+    if (!X || !QKV || !CTX || !MSG || !HID || !ENC || !SIM || !Z || !ST) return fail(MG_ERR_HIP, "workspace allocation failed");
+
+    HIPCHK(hipMemcpyAsync(X, desc0, T0 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(X + T0 * 256, desc1, T1 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    {
+        ProfScope ps(h, s, "lg.posenc");
+        launch_posenc(kpts0, kpts1, size0, size1, h->Wr, B, M, N, ENC, s);
+    }
+    if (int rc = tap_copy(h, "lg.enc", ENC, T * 64, s)) return rc;
+
+    auto ffn = [&](const LgBlock& blk, const char* tag) {
+        {
+            ProfScope ps(h, s, "lg.gemm.ffn0");
+            GemmArgs g = lin_args(blk.ffn0, X, 256, (int)T, HID, 512);
+            g.A1 = MSG; g.lda1 = 256; g.ksplit = 256;
+            launch_gemm(g, s);
+        }
+        {
+            ProfScope ps(h, s, "lg.ln_gelu");
+            launch_ln_gelu(HID, (long long)T, 512, blk.ln_g, blk.ln_b, 1e-5f, s);
+        }
+        {
+            ProfScope ps(h, s, "lg.gemm.ffn3");
+            GemmArgs g = lin_args(blk.ffn3, HID, 512, (int)T, X, 256);
+            g.residual = X; g.ldr = 256;
+            launch_gemm(g, s);
+        }
+        (void)tag;
+    };
+
+    for (int i = 0; i < conf->n_layers; ++i) {
+        const LgBlock& sb = h->lg_self[i];
+        {
+            ProfScope ps(h, s, "lg.gemm.qkv");
+            GemmArgs g = lin_args(sb.proj, X, 256, (int)T, QKV, 768);
+            g.enc = ENC; g.rotary_cols = 512; g.scale = 0.125f; g.scale_cols = 256;
+            launch_gemm(g, s);
+        }
+        {
+            ProfScope ps(h, s, "lg.attn.self");
+            AttnArgs a;
+            a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
+            a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = 0;
+            launch_attention(a, s);
+        }
+        {
+            ProfScope ps(h, s, "lg.gemm.out");
+            GemmArgs g = lin_args(sb.out, CTX, 256, (int)T, MSG, 256);
+            launch_gemm(g, s);
+        }
+        ffn(sb, "self");
+        if (int rc = tap_copy(h, "lg.self" + std::to_string(i), X, T * 256, s)) return rc;
+
+        const LgBlock& cb = h->lg_cross[i];
+        {
+            ProfScope ps(h, s, "lg.gemm.qkv_cross");
+            GemmArgs g = lin_args(cb.proj, X, 256, (int)T, QKV, 512);
+            g.scale = 0.35355339059327373f;  // (dim_head^-0.5)^0.5, lightglue.py:200
+            g.scale_cols = 256;
+            launch_gemm(g, s);
+        }
+        {
+            ProfScope ps(h, s, "lg.attn.cross");
+            AttnArgs a;
+            a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 512; a.q_col = 0; a.k_col = 0; a.v_col = 256;
+            a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = 1;
+            launch_attention(a, s);
+        }
+        {
+            ProfScope ps(h, s, "lg.gemm.out");
+            GemmArgs g = lin_args(cb.out, CTX, 256, (int)T, MSG, 256);
+            launch_gemm(g, s);
+        }
+        ffn(cb, "cross");
+        if (int rc = tap_copy(h, "lg.layer" + std::to_string(i), X, T * 256, s)) return rc;
+    }
+
+    // assignment head (lightglue.py:265-303)
+    float* MD = QKV;  // reuse: (T,256) projected descriptors
+    {
+        ProfScope ps(h, s, "lg.gemm.final_proj");
+        GemmArgs g = lin_args(h->final_proj, X, 256, (int)T, MD, 256);
+        g.scale = 0.25f;  // / 256^(1/4)
+        g.scale_cols = 256;
+        launch_gemm(g, s);
+    }
+    {
+        ProfScope ps(h, s, "lg.gemm.sim");
+        GemmArgs g;
+        g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+        g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+        g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
+        g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
+        launch_gemm(g, s);
+    }
+    {
+        ProfScope ps(h, s, "lg.assign");
+        launch_matchability(X, (long long)T, h->match_w, h->match_b, Z, s);
+        AssignArgs a;
+        a.sim = SIM; a.z0 = Z; a.z1 = Z + T0; a.B = B; a.M = M; a.N = N; a.threshold = conf->filter_threshold;
+        a.row_mx = ST; a.row_ls = ST + T0; a.row_best = ST + 2 * T0;
+        a.row_arg = reinterpret_cast<int*>(ST + 3 * T0);
+        float* cbase = ST + 4 * T0;
+        a.col_mx = cbase; a.col_ls = cbase + T1; a.col_best = cbase + 2 * T1;
+        a.col_arg = reinterpret_cast<int*>(cbase + 3 * T1);
+        a.log_assignment = log_assignment;
+        a.m0 = reinterpret_cast<long long*>(matches0); a.m1 = reinterpret_cast<long long*>(matches1);
+        a.ms0 = mscores0; a.ms1 = mscores1;
+        launch_assignment(a, s);
+    }
+    if (ref_desc0) HIPCHK(hipMemcpyAsync(ref_desc0, X, T0 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (ref_desc1) HIPCHK(hipMemcpyAsync(ref_desc1, X + T0 * 256, T1 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mg_test_linear(mg_handle h, const float* A, const float* W_host, const float* bias_host, int M, int N, int K, float* C, void* stream) {
+    if (!h || !A || !W_host || !C || M < 1 || N < 1 || K < 32 || (K % 32)) return fail(MG_ERR_ARG, "bad argument (K must be a multiple of 32)");
+    HIPCHK(hipSetDevice(h->device));
+    LinLayer L;
+    std::vector<const float*> rows(N);
+    for (int n = 0; n < N; ++n) rows[n] = W_host + (size_t)n * K;
+    std::vector<float> bias;
+    if (bias_host) bias.assign(bias_host, bias_host + N);
+    if (int rc = prep_linear_rows(h, rows, bias, K, &L)) return rc;
+    GemmArgs g = lin_args(L, A, K, M, C, N);
+    launch_gemm(g, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    return 0;
+}
+
+}  // extern "C"

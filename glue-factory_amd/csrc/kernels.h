@@ -1,0 +1,134 @@
+// Host-side launchers of the HIP kernels (internal; the public surface is include/matchglue.h).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// ---- gemm.hip : C[M,N] = A[M,K] * W[N,K]^T (+ epilogue), fp32-input MFMA --------------------------
+struct GemmArgs {
+    const float* A0 = nullptr;  // rows of K0 = ksplit floats (row stride lda0)
+    int lda0 = 0;
+    const float* A1 = nullptr;  // optional second source for k >= ksplit (concat-free FFN)
+    int lda1 = 0;
+    int ksplit = 0;             // == K when A1 is unused
+    const float* W = nullptr;   // tiled [K/8][Npad][8] (w_rowmajor = 0) or row-major [N][ldw]
+    int Npad = 0;
+    int w_rowmajor = 0;
+    int ldw = 0;
+    const float* bias = nullptr;
+    float* C = nullptr;
+    int ldc = 0;
+    int M = 0, N = 0, K = 0;
+    // epilogue: v = acc + bias; rotary (cols < rotary_cols); relu; v*post_scale+post_shift;
+    //           v *= scale (cols < scale_cols); v += residual
+    const float* enc = nullptr;  // (M,64): cos[32] | sin[32] per row
+    int rotary_cols = 0;
+    int relu = 0;
+    const float* post_scale = nullptr;
+    const float* post_shift = nullptr;
+    float scale = 1.f;
+    int scale_cols = 0;
+    const float* residual = nullptr;
+    int ldr = 0;
+    // batching (blockIdx.z): element strides
+    int batch = 1;
+    long long strideA = 0, strideW = 0, strideC = 0;
+};
+void launch_gemm(const GemmArgs& a, hipStream_t s);
+
+// ---- conv.hip ------------------------------------------------------------------------------------
+struct ConvArgs {
+    const float* in = nullptr;   // NHWC (B,H,W,Cin)
+    const float* Wt = nullptr;   // tiled [Cin/8][9][CoutPad][8]
+    int CoutPad = 0;
+    const float* bias = nullptr;
+    const float* post_scale = nullptr;  // optional per-channel affine after ReLU (BatchNorm of SP-open)
+    const float* post_shift = nullptr;
+    float* out = nullptr;        // NHWC (B,Ho,Wo,Cout), Ho = pool ? H/2 : H
+    int B = 0, H = 0, W = 0, Cin = 0, Cout = 0;
+    int pool = 0;
+    int relu = 1;
+};
+void launch_conv3x3(const ConvArgs& a, hipStream_t s);
+
+struct Conv1aArgs {
+    const float* image = nullptr;  // NCHW (B,C,H,W), C in {1,3}
+    int B = 0, C = 0, H = 0, W = 0;
+    const float* w = nullptr;      // [64][9]
+    const float* bias = nullptr;
+    const float* post_scale = nullptr;
+    const float* post_shift = nullptr;
+    float* out = nullptr;          // NHWC (B,H,W,64)
+};
+void launch_conv1a(const Conv1aArgs& a, hipStream_t s);
+
+// ---- sp_post.hip ---------------------------------------------------------------------------------
+void launch_softmax_d2s(const float* logits, int ld, int B, int hc, int wc, float* heat, hipStream_t s);
+void launch_l2norm_rows(float* x, long long rows, int dim, hipStream_t s);
+void launch_nhwc_to_nchw(const float* in, float* out, int B, int HW, int C, hipStream_t s);
+void launch_nchw_to_nhwc(const float* in, float* out, int B, int HW, int C, hipStream_t s);
+struct DetectArgs {
+    const float* heat = nullptr;  // (B,Hs,Ws)
+    int B = 0, Hs = 0, Ws = 0;
+    int radius = 0, border = 0, K = 0;
+    float threshold = 0.f;
+    const float* image_size = nullptr;  // (B,2) (w,h) or null
+    unsigned long long* cand = nullptr; // (B, Hs*Ws) candidate keys
+    int* counts = nullptr;              // (B)
+    float* nms_out = nullptr;           // optional
+    float* keypoints = nullptr;         // (B,K,2)
+    float* scores = nullptr;            // (B,K)
+    int* num_valid = nullptr;           // (B)
+};
+void launch_detect(const DetectArgs& a, hipStream_t s);
+struct SampleArgs {
+    const float* keypoints = nullptr;  // (B,K,2) (x,y)+0.5
+    const float* dense = nullptr;      // NHWC (B,hc,wc,256), normalised
+    int B = 0, K = 0, hc = 0, wc = 0;
+    int mode = 0;
+    float* desc = nullptr;             // (B,K,256)
+};
+void launch_sample(const SampleArgs& a, hipStream_t s);
+
+// ---- attention.hip -------------------------------------------------------------------------------
+struct AttnArgs {
+    const float* q = nullptr;  // rows of `ld` floats; head h occupies cols [q_col + 64h, +64)
+    const float* k = nullptr;
+    const float* v = nullptr;
+    int ld = 0;
+    int q_col = 0, k_col = 0, v_col = 0;
+    float* out = nullptr;      // (tokens,256): head h -> cols [64h, +64)
+    int ldo = 0;
+    int B = 0, M = 0, N = 0;   // pairs, tokens in image 0 / image 1 (rows: image-0 block, then image-1)
+    int heads = 4;
+    int cross = 0;             // 0: each sequence attends to itself; 1: to the other image of its pair
+};
+void launch_attention(const AttnArgs& a, hipStream_t s);
+
+// ---- lg_misc.hip ---------------------------------------------------------------------------------
+void launch_posenc(const float* kpts0, const float* kpts1, const float* size0, const float* size1, const float* Wr,
+                   int B, int M, int N, float* enc, hipStream_t s);
+void launch_ln_gelu(float* x, long long rows, int dim, const float* gamma, const float* beta, float eps, hipStream_t s);
+void launch_matchability(const float* x, long long rows, const float* w, float bias, float* z, hipStream_t s);
+struct AssignArgs {
+    const float* sim = nullptr;  // (B,M,N)
+    const float* z0 = nullptr;   // (B*M) matchability logits of image 0
+    const float* z1 = nullptr;   // (B*N)
+    int B = 0, M = 0, N = 0;
+    float threshold = 0.f;
+    // workspace
+    float* row_mx = nullptr;     // (B,M) max_j sim
+    float* row_ls = nullptr;     // (B,M) log sum_j exp(sim - max)
+    float* col_mx = nullptr;     // (B,N)
+    float* col_ls = nullptr;     // (B,N)
+    float* row_best = nullptr;   // (B,M) max_j S[i,j]
+    int* row_arg = nullptr;      // (B,M)
+    float* col_best = nullptr;   // (B,N)
+    int* col_arg = nullptr;      // (B,N)
+    // outputs
+    float* log_assignment = nullptr;  // optional (B,M+1,N+1)
+    long long* m0 = nullptr;
+    long long* m1 = nullptr;
+    float* ms0 = nullptr;
+    float* ms1 = nullptr;
+};
+void launch_assignment(const AssignArgs& a, hipStream_t s);

@@ -1,0 +1,275 @@
+// LightGlue byte-bound kernels: positional encoding, LayerNorm+GELU, matchability, dual-softmax
+// assignment and mutual-arg-max filtering.  Coalesced row/column sweeps, wave shuffles; no MFMA.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// lightglue.py:22-33 + :46-59.  enc[token] = cos(Wr*kn)[32] | sin(Wr*kn)[32]; the reference's
+// repeat_interleave(2) is an indexing matter handled by the rotary epilogue (frequency = d>>1).
+// One block per sequence (image b of side s); size == NULL falls back to the keypoint extent.
+__global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ k0, const float* __restrict__ k1,
+                                                    const float* __restrict__ size0, const float* __restrict__ size1,
+                                                    const float* __restrict__ Wr, int B, int M, int N, float* __restrict__ enc) {
+    __shared__ float s_red[4][4];
+    __shared__ float s_size[2];
+    const int seq = blockIdx.x, side = seq >= B, b = seq - side * B;
+    const int L = side ? N : M;
+    const float* kp = (side ? k1 : k0) + (long long)b * L * 2;
+    const float* size = side ? size1 : size0;
+    float* e = enc + (side ? ((long long)B * M + (long long)b * N) : (long long)b * M) * 64;
+    if (size) {
+        if (threadIdx.x < 2) s_size[threadIdx.x] = size[2 * b + threadIdx.x];
+    } else {
+        float mnx = __builtin_inff(), mny = __builtin_inff(), mxx = -__builtin_inff(), mxy = -__builtin_inff();
+        for (int i = threadIdx.x; i < L; i += 256) {
+            const float x = kp[2 * i], y = kp[2 * i + 1];
+            mnx = fminf(mnx, x); mxx = fmaxf(mxx, x); mny = fminf(mny, y); mxy = fmaxf(mxy, y);
+        }
+        mnx = -wave_max(-mnx); mny = -wave_max(-mny); mxx = wave_max(mxx); mxy = wave_max(mxy);
+        if ((threadIdx.x & 63) == 0) {
+            const int w = threadIdx.x >> 6;
+            s_red[w][0] = mnx; s_red[w][1] = mny; s_red[w][2] = mxx; s_red[w][3] = mxy;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int w = 1; w < 4; ++w) {
+                s_red[0][0] = fminf(s_red[0][0], s_red[w][0]); s_red[0][1] = fminf(s_red[0][1], s_red[w][1]);
+                s_red[0][2] = fmaxf(s_red[0][2], s_red[w][2]); s_red[0][3] = fmaxf(s_red[0][3], s_red[w][3]);
+            }
+            s_size[0] = __fsub_rn(__fadd_rn(1.f, s_red[0][2]), s_red[0][0]);
+            s_size[1] = __fsub_rn(__fadd_rn(1.f, s_red[0][3]), s_red[0][1]);
+        }
+    }
+    __syncthreads();
+    const float sw = s_size[0], sh = s_size[1];
+    const float shx = sw / 2.f, shy = sh / 2.f, sc = fmaxf(sw, sh) / 2.f;
+    for (int i = threadIdx.x; i < L * 32; i += 256) {
+        const int tok = i >> 5, f = i & 31;
+        const float x = __fdiv_rn(__fsub_rn(kp[2 * tok], shx), sc);
+        const float y = __fdiv_rn(__fsub_rn(kp[2 * tok + 1], shy), sc);
+        const float pr = __fadd_rn(__fmul_rn(x, Wr[2 * f]), __fmul_rn(y, Wr[2 * f + 1]));
+        e[(long long)tok * 64 + f] = cosf(pr);
+        e[(long long)tok * 64 + 32 + f] = sinf(pr);
+    }
+}
+
+// lightglue.py:139-140 -- LayerNorm(512, eps) then exact (erf) GELU, in place.  One wave per row.
+__global__ __launch_bounds__(256) void ln_gelu_kernel(float* __restrict__ x, long long rows, int dim, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float eps) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* p = x + row * dim;
+    f32x4 v[2];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        v[i] = *reinterpret_cast<const f32x4*>(p + i * 256 + lane * 4);
+        sum += v[i].x + v[i].y + v[i].z + v[i].w;
+    }
+    const float mean = wave_sum(sum) / (float)dim;
+    float sq = 0.f;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float d = v[i][j] - mean;
+            sq += d * d;
+        }
+    const float var = wave_sum(sq) / (float)dim;
+    const float rstd = 1.f / sqrtf(var + eps);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 256 + lane * 4);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + i * 256 + lane * 4);
+        f32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float y = (v[i][j] - mean) * rstd * g[j] + bb[j];
+            o[j] = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+        }
+        *reinterpret_cast<f32x4*>(p + i * 256 + lane * 4) = o;
+    }
+}
+
+// lightglue.py:270,279-280 -- matchability logit z = <x, w> + b per token.  One wave per row of 256.
+__global__ __launch_bounds__(256) void matchability_kernel(const float* __restrict__ x, long long rows, const float* __restrict__ w, float bias,
+                                                          float* __restrict__ z) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + row * 256 + lane * 4);
+    const f32x4 c = *reinterpret_cast<const f32x4*>(w + lane * 4);
+    const float d = wave_sum(a.x * c.x + a.y * c.y + a.z * c.z + a.w * c.w);
+    if (lane == 0) z[row] = d + bias;
+}
+
+__device__ __forceinline__ float log_sigmoid(float x) { return fminf(x, 0.f) - log1pf(expf(-fabsf(x))); }
+
+// Row statistics of sim: max_j and log sum_j exp(sim - max).  One wave per row.
+__global__ __launch_bounds__(256) void assign_row_stats(const AssignArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= (long long)p.B * p.M) return;
+    const float* s = p.sim + row * p.N;
+    float m = -__builtin_inff();
+    for (int j = lane; j < p.N; j += 64) m = fmaxf(m, s[j]);
+    m = wave_max(m);
+    float acc = 0.f;
+    for (int j = lane; j < p.N; j += 64) acc += expf(s[j] - m);
+    acc = wave_sum(acc);
+    if (lane == 0) { p.row_mx[row] = m; p.row_ls[row] = logf(acc); }
+}
+
+// Column statistics: 64 columns per block, 4 row groups, online max/sum then an LDS combine.
+__global__ __launch_bounds__(256) void assign_col_stats(const AssignArgs p) {
+    __shared__ float s_m[4][64], s_l[4][64];
+    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+    const float* s = p.sim + (long long)b * p.M * p.N;
+    float m = -__builtin_inff(), l = 0.f;
+    if (c < p.N)
+        for (int i = g; i < p.M; i += 4) {
+            const float v = s[(long long)i * p.N + c];
+            if (v > m) { l = l * expf(m - v) + 1.f; m = v; } else { l += expf(v - m); }
+        }
+    s_m[g][threadIdx.x & 63] = m;
+    s_l[g][threadIdx.x & 63] = l;
+    __syncthreads();
+    if (g == 0 && c < p.N) {
+        float mm = fmaxf(fmaxf(s_m[0][threadIdx.x], s_m[1][threadIdx.x]), fmaxf(s_m[2][threadIdx.x], s_m[3][threadIdx.x]));
+        float ll = 0.f;
+        for (int k = 0; k < 4; ++k)
+            if (s_l[k][threadIdx.x] > 0.f) ll += s_l[k][threadIdx.x] * expf(s_m[k][threadIdx.x] - mm);
+        p.col_mx[(long long)b * p.N + c] = mm;
+        p.col_ls[(long long)b * p.N + c] = logf(ll);
+    }
+}
+
+__device__ __forceinline__ float assign_value(float sim, float rmx, float rls, float cmx, float cls, float cert) {
+    // (log_softmax rows + log_softmax cols) + certainties, in the reference's association (lightglue.py:255-259)
+    const float s0 = __fsub_rn(__fsub_rn(sim, rmx), rls);
+    const float s1 = __fsub_rn(__fsub_rn(sim, cmx), cls);
+    return __fadd_rn(__fadd_rn(s0, s1), cert);
+}
+
+// Assemble S (optional write of the (M+1)x(N+1) matrix) and the row arg-max.  One wave per row.
+__global__ __launch_bounds__(256) void assign_rows(const AssignArgs p) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long rows = (long long)p.B * (p.M + 1);
+    if (row >= rows) return;
+    const int b = (int)(row / (p.M + 1)), i = (int)(row - (long long)b * (p.M + 1));
+    float* la = p.log_assignment ? p.log_assignment + row * (p.N + 1) : nullptr;
+    if (i == p.M) {  // last row: unmatched bin of image 1
+        if (la) {
+            for (int j = lane; j < p.N; j += 64) la[j] = log_sigmoid(-p.z1[(long long)b * p.N + j]);
+            if (lane == 0) la[p.N] = 0.f;
+        }
+        return;
+    }
+    const long long r = (long long)b * p.M + i;
+    const float* s = p.sim + r * p.N;
+    const float rmx = p.row_mx[r], rls = p.row_ls[r], z0 = p.z0[r];
+    const float ls0 = log_sigmoid(z0);
+    float best = -__builtin_inff();
+    int arg = 0x7fffffff;
+    for (int j = lane; j < p.N; j += 64) {
+        const long long c = (long long)b * p.N + j;
+        const float cert = __fadd_rn(ls0, log_sigmoid(p.z1[c]));
+        const float v = assign_value(s[j], rmx, rls, p.col_mx[c], p.col_ls[c], cert);
+        if (la) la[j] = v;
+        if (v > best) { best = v; arg = j; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ob = __shfl_xor(best, o);
+        const int oa = __shfl_xor(arg, o);
+        if (ob > best || (ob == best && oa < arg)) { best = ob; arg = oa; }
+    }
+    if (lane == 0) {
+        p.row_best[r] = best;
+        p.row_arg[r] = arg;
+        if (la) la[p.N] = log_sigmoid(-z0);
+    }
+}
+
+// Column arg-max of S: 64 columns per block, 4 row groups.
+__global__ __launch_bounds__(256) void assign_cols(const AssignArgs p) {
+    __shared__ float s_b[4][64];
+    __shared__ int s_a[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, g = threadIdx.x >> 6;
+    const float* s = p.sim + (long long)b * p.M * p.N;
+    float best = -__builtin_inff();
+    int arg = 0x7fffffff;
+    if (c < p.N) {
+        const long long cc = (long long)b * p.N + c;
+        const float cmx = p.col_mx[cc], cls = p.col_ls[cc], ls1 = log_sigmoid(p.z1[cc]);
+        for (int i = g; i < p.M; i += 4) {
+            const long long r = (long long)b * p.M + i;
+            const float cert = __fadd_rn(log_sigmoid(p.z0[r]), ls1);
+            const float v = assign_value(s[(long long)i * p.N + c], p.row_mx[r], p.row_ls[r], cmx, cls, cert);
+            if (v > best) { best = v; arg = i; }
+        }
+    }
+    s_b[g][cl] = best;
+    s_a[g][cl] = arg;
+    __syncthreads();
+    if (g == 0 && c < p.N) {
+        for (int k = 1; k < 4; ++k)
+            if (s_b[k][cl] > best || (s_b[k][cl] == best && s_a[k][cl] < arg)) { best = s_b[k][cl]; arg = s_a[k][cl]; }
+        p.col_best[(long long)b * p.N + c] = best;
+        p.col_arg[(long long)b * p.N + c] = arg;
+    }
+}
+
+// lightglue.py:287-303 -- mutual check, exp, threshold.
+__global__ __launch_bounds__(256) void assign_filter(const AssignArgs p) {
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    const int* ra = p.row_arg + (long long)b * p.M;
+    const int* ca = p.col_arg + (long long)b * p.N;
+    const float* rb = p.row_best + (long long)b * p.M;
+    if (i < p.M) {
+        const int j = ra[i];
+        const bool mutual = ca[j] == i;
+        const float sc = mutual ? expf(rb[i]) : 0.f;
+        p.ms0[(long long)b * p.M + i] = sc;
+        p.m0[(long long)b * p.M + i] = (mutual && sc > p.threshold) ? j : -1;
+    }
+    if (i < p.N) {
+        const int k = ca[i];          // row index matched to column i
+        const bool mutual1 = ra[k] == i;
+        const bool mutual0 = ca[ra[k]] == k;
+        const float sc0 = mutual0 ? expf(rb[k]) : 0.f;
+        const float sc = mutual1 ? sc0 : 0.f;
+        p.ms1[(long long)b * p.N + i] = sc;
+        p.m1[(long long)b * p.N + i] = (mutual1 && mutual0 && sc0 > p.threshold) ? k : -1;
+    }
+}
+
+}  // namespace
+
+void launch_posenc(const float* kpts0, const float* kpts1, const float* size0, const float* size1, const float* Wr, int B, int M,
+                   int N, float* enc, hipStream_t s) {
+    hipLaunchKernelGGL(posenc_kernel, dim3(2 * B), dim3(256), 0, s, kpts0, kpts1, size0, size1, Wr, B, M, N, enc);
+}
+
+void launch_ln_gelu(float* x, long long rows, int dim, const float* gamma, const float* beta, float eps, hipStream_t s) {
+    hipLaunchKernelGGL(ln_gelu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, dim, gamma, beta, eps);
+}
+
+void launch_matchability(const float* x, long long rows, const float* w, float bias, float* z, hipStream_t s) {
+    hipLaunchKernelGGL(matchability_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, w, bias, z);
+}
+
+void launch_assignment(const AssignArgs& a, hipStream_t s) {
+    const long long rows = (long long)a.B * a.M;
+    hipLaunchKernelGGL(assign_row_stats, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(assign_col_stats, dim3((a.N + 63) / 64, a.B), dim3(256), 0, s, a);
+    const long long rows1 = (long long)a.B * (a.M + 1);
+    hipLaunchKernelGGL(assign_rows, dim3((unsigned)((rows1 + 3) / 4)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(assign_cols, dim3((a.N + 63) / 64, a.B), dim3(256), 0, s, a);
+    const int L = a.M > a.N ? a.M : a.N;
+    hipLaunchKernelGGL(assign_filter, dim3((L + 255) / 256, a.B), dim3(256), 0, s, a);
+}

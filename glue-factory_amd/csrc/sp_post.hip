@@ -1,0 +1,371 @@
+// SuperPoint post-processing kernels: detector soft-max + depth-to-space, L2 normalisation,
+// NMS + border + threshold + top-k keypoint selection, bilinear descriptor sampling.
+// All HBM-bound / LDS-bound byte work: coalesced loads, LDS tiles, wave shuffles -- no MFMA.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+// ---------------------------------------------------------------------------------------------
+// superpoint.py:226-230 -- softmax over the 65 logits of a cell, drop the dustbin, and scatter the
+// 64 probabilities to the 8x8 pixels of the cell.  One wave per cell, lane c = logit c.
+__global__ __launch_bounds__(256) void softmax_d2s_kernel(const float* __restrict__ logits, int ld, int B, int hc, int wc,
+                                                         float* __restrict__ heat) {
+    const int lane = threadIdx.x & 63;
+    const long long cell = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const long long ncell = (long long)B * hc * wc;
+    if (cell >= ncell) return;
+    const float* lg = logits + cell * ld;
+    const float v = lg[lane];
+    const float dust = lg[64];
+    const float m = fmaxf(wave_max(v), dust);
+    const float e = expf(v - m);
+    const float sum = wave_sum(e) + expf(dust - m);
+    const float pr = e / sum;
+    const int b = (int)(cell / (hc * wc));
+    const int rem = (int)(cell - (long long)b * hc * wc);
+    const int cy = rem / wc, cx = rem - cy * wc;
+    const int Ws = wc * 8;
+    heat[((long long)b * hc * 8 + cy * 8 + (lane >> 3)) * Ws + cx * 8 + (lane & 7)] = pr;
+}
+
+// F.normalize(p=2, eps=1e-12) over rows of `dim` floats (dim == 256: one wave per row, 4 floats per lane).
+__global__ __launch_bounds__(256) void l2norm_rows_kernel(float* __restrict__ x, long long rows, int dim) {
+    const int lane = threadIdx.x & 63;
+    const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    float* p = x + row * dim;
+    float ss = 0.f;
+    for (int c = lane * 4; c < dim; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+        ss += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+    }
+    ss = wave_sum(ss);
+    const float d = fmaxf(sqrtf(ss), 1e-12f);
+    for (int c = lane * 4; c < dim; c += 256) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(p + c);
+        v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+        *reinterpret_cast<f32x4*>(p + c) = v;
+    }
+}
+
+// (B,HW,C) <-> (B,C,HW) through a 32x33 LDS tile.
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int Cc) {
+    // in: (B,R,Cc) -> out: (B,Cc,R)
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const float* src = in + (long long)b * R * Cc;
+    float* dst = out + (long long)b * R * Cc;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, c = c0 + tx;
+        tile[i][tx] = (r < R && c < Cc) ? src[(long long)r * Cc + c] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int c = c0 + i, r = r0 + tx;
+        if (r < R && c < Cc) dst[(long long)c * R + r] = tile[tx][i];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// simple_nms (superpoint.py:60-80) + border removal (:243-254) + threshold (:257), one 32x32 output
+// tile per block with a 5r halo (the dependency radius of the three keep/suppress rounds).
+// max_pool2d pads with -inf, so everything outside the image is -inf / "not kept".
+constexpr int NMS_TILE = 32;
+constexpr int NMS_TMAX = NMS_TILE + 10 * 4;  // radius <= 4
+
+__device__ __forceinline__ void pool_pass(const float* src, float* tmp, float* dst, int T, int r) {
+    const int n = T * T;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int y = i / T, x = i - y * T;
+        const int lo = max(x - r, 0), hi = min(x + r, T - 1);
+        float m = src[y * T + lo];
+        for (int k = lo + 1; k <= hi; ++k) m = fmaxf(m, src[y * T + k]);
+        tmp[i] = m;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int y = i / T, x = i - y * T;
+        const int lo = max(y - r, 0), hi = min(y + r, T - 1);
+        float m = tmp[lo * T + x];
+        for (int k = lo + 1; k <= hi; ++k) m = fmaxf(m, tmp[k * T + x]);
+        dst[i] = m;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
+    __shared__ float s_s[NMS_TMAX * NMS_TMAX];
+    __shared__ float s_a[NMS_TMAX * NMS_TMAX];
+    __shared__ float s_t[NMS_TMAX * NMS_TMAX];
+    __shared__ unsigned char s_keep[NMS_TMAX * NMS_TMAX];
+    __shared__ unsigned char s_supp[NMS_TMAX * NMS_TMAX];
+
+    const int r = p.radius, halo = 5 * r, T = NMS_TILE + 2 * halo, n = T * T;
+    const int b = blockIdx.z;
+    const int y0 = blockIdx.y * NMS_TILE - halo, x0 = blockIdx.x * NMS_TILE - halo;
+    const float* heat = p.heat + (long long)b * p.Hs * p.Ws;
+    const float NEG = -__builtin_inff();
+
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int y = i / T, x = i - y * T;
+        const int gy = y0 + y, gx = x0 + x;
+        s_s[i] = (gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws) ? heat[(long long)gy * p.Ws + gx] : NEG;
+    }
+    __syncthreads();
+    if (r > 0) {
+        pool_pass(s_s, s_t, s_a, T, r);
+        for (int i = threadIdx.x; i < n; i += 256) s_keep[i] = (s_s[i] != NEG) && (s_s[i] == s_a[i]);
+        __syncthreads();
+        for (int it = 0; it < 2; ++it) {
+            for (int i = threadIdx.x; i < n; i += 256) s_a[i] = s_keep[i] ? 1.f : 0.f;
+            __syncthreads();
+            pool_pass(s_a, s_t, s_a, T, r);
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const unsigned char sp = s_a[i] > 0.f;
+                s_supp[i] = sp;
+                s_a[i] = (s_s[i] == NEG) ? NEG : (sp ? 0.f : s_s[i]);
+            }
+            __syncthreads();
+            pool_pass(s_a, s_t, s_a, T, r);
+            for (int i = threadIdx.x; i < n; i += 256) {
+                if (s_s[i] == NEG) continue;
+                const float rest = s_supp[i] ? 0.f : s_s[i];
+                if ((rest == s_a[i]) && !s_supp[i]) s_keep[i] = 1;
+            }
+            __syncthreads();
+        }
+    } else {
+        for (int i = threadIdx.x; i < n; i += 256) s_keep[i] = 1;  // radius 0: every pixel is its own maximum
+        __syncthreads();
+    }
+
+    // interior 32x32: border mask, optional dump, candidate append
+    int hlim = p.Hs, wlim = p.Ws;
+    if (p.image_size) {
+        wlim = (int)p.image_size[2 * b];
+        hlim = (int)p.image_size[2 * b + 1];
+    }
+    for (int i = threadIdx.x; i < NMS_TILE * NMS_TILE; i += 256) {
+        const int ty = i >> 5, tx = i & 31;
+        const int gy = blockIdx.y * NMS_TILE + ty, gx = blockIdx.x * NMS_TILE + tx;
+        if (gy >= p.Hs || gx >= p.Ws) continue;
+        const int li = (ty + halo) * T + tx + halo;
+        float v = s_keep[li] ? s_s[li] : 0.f;
+        if (p.border > 0) {
+            if (gy < p.border || gx < p.border || gy >= hlim - p.border || gx >= wlim - p.border) v = -1.f;
+        }
+        const unsigned idx = (unsigned)(gy * p.Ws + gx);
+        if (p.nms_out) p.nms_out[(long long)b * p.Hs * p.Ws + idx] = v;
+        if (v > p.threshold) {
+            const int pos = atomicAdd(&p.counts[b], 1);
+            p.cand[(long long)b * p.Hs * p.Ws + pos] = ((unsigned long long)float_to_key(v) << 32) | (0xFFFFFFFFu - idx);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// top_k_keypoints (superpoint.py:83-87, :286-302): per image, the K candidates with the largest
+// (score, then lowest index) key, sorted descending; if there are at most K candidates they are
+// returned in row-major order.  Radix-select (8 x 8-bit passes over the 64-bit keys, per-image
+// block) finds the K-th key, the survivors are compacted into LDS and bitonic-sorted there.
+constexpr int SEL_THREADS = 1024;
+constexpr int SEL_MAXK = 4096;
+
+__global__ __launch_bounds__(SEL_THREADS) void select_kernel(const DetectArgs p) {
+    __shared__ unsigned long long s_keys[SEL_MAXK];
+    __shared__ int s_hist[256];
+    __shared__ unsigned long long s_prefix;
+    __shared__ int s_want, s_cnt;
+
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int n = p.counts[b];
+    const int K = p.K;
+    const unsigned long long* cand = p.cand + (long long)b * p.Hs * p.Ws;
+    int P = 1;
+    while (P < K) P <<= 1;
+    const int nsel = n < K ? n : K;
+
+    for (int i = tid; i < P; i += SEL_THREADS) s_keys[i] = 0ull;
+    __syncthreads();
+
+    if (n <= K) {
+        // row-major order == ascending index == descending (0xFFFFFFFF - idx): sort on the low word
+        for (int i = tid; i < n; i += SEL_THREADS) {
+            const unsigned long long k = cand[i];
+            s_keys[i] = (k << 32) | (k >> 32);
+        }
+    } else {
+        if (tid == 0) { s_prefix = 0ull; s_want = K; s_cnt = 0; }
+        __syncthreads();
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            for (int i = tid; i < 256; i += SEL_THREADS) s_hist[i] = 0;
+            __syncthreads();
+            const unsigned long long prefix = s_prefix;
+            for (int i0 = 0; i0 < n; i0 += SEL_THREADS) {
+                const int i = i0 + tid;
+                bool act = false;
+                int bin = 0;
+                if (i < n) {
+                    const unsigned long long k = cand[i];
+                    act = (pass == 0) || ((k >> (shift + 8)) == (prefix >> (shift + 8)));
+                    bin = (int)((k >> shift) & 255);
+                }
+                // wave-aggregate when every active lane hits the same bin (the high bytes of scores
+                // are nearly constant), otherwise plain LDS atomics
+                const unsigned long long am = __ballot(act);
+                if (am) {
+                    const int lead = __ffsll((long long)am) - 1;
+                    const int lbin = __shfl(bin, lead);
+                    const unsigned long long same = __ballot(act && bin == lbin);
+                    if (same == am) {
+                        if (lane == lead) atomicAdd(&s_hist[lbin], __popcll(am));
+                    } else if (act) {
+                        atomicAdd(&s_hist[bin], 1);
+                    }
+                }
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int want = s_want, cum = 0, d = 255;
+                for (; d > 0; --d) {
+                    if (cum + s_hist[d] >= want) break;
+                    cum += s_hist[d];
+                }
+                s_prefix = prefix | ((unsigned long long)d << shift);
+                s_want = want - cum;
+            }
+            __syncthreads();
+        }
+        const unsigned long long kth = s_prefix;
+        for (int i = tid; i < n; i += SEL_THREADS) {
+            const unsigned long long k = cand[i];
+            if (k >= kth) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < SEL_MAXK) s_keys[pos] = k;
+            }
+        }
+    }
+    __syncthreads();
+
+    // bitonic sort, descending, P elements
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int j = k >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < P; i += SEL_THREADS) {
+                const int ixj = i ^ j;
+                if (ixj > i) {
+                    const unsigned long long a = s_keys[i], c = s_keys[ixj];
+                    const bool desc = ((i & k) == 0);
+                    if (desc ? (a < c) : (a > c)) { s_keys[i] = c; s_keys[ixj] = a; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    for (int i = tid; i < K; i += SEL_THREADS) {
+        float kx = 0.f, ky = 0.f, sc = 0.f;
+        if (i < nsel) {
+            unsigned long long k = s_keys[i];
+            if (n <= K) k = (k << 32) | (k >> 32);
+            const unsigned idx = 0xFFFFFFFFu - (unsigned)(k & 0xFFFFFFFFull);
+            sc = key_to_float((unsigned)(k >> 32));
+            const int y = idx / p.Ws, x = idx - y * p.Ws;
+            kx = (float)x + 0.5f;
+            ky = (float)y + 0.5f;
+        }
+        p.keypoints[((long long)b * K + i) * 2] = kx;
+        p.keypoints[((long long)b * K + i) * 2 + 1] = ky;
+        p.scores[(long long)b * K + i] = sc;
+    }
+    if (tid == 0) p.num_valid[b] = nsel;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Descriptor sampling (superpoint.py:117-149, superpoint_open.py:20-31): grid_sample(bilinear, zero
+// padding) of the normalised dense map at each keypoint, then L2-normalise.  One wave per keypoint,
+// lane = 4 channels, so each corner is one coalesced 1 KiB read of the NHWC map.
+__global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p, float divx, float divy) {
+    const int lane = threadIdx.x & 63;
+    const long long kp = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (kp >= (long long)p.B * p.K) return;
+    const int b = (int)(kp / p.K);
+    const float xi = p.keypoints[kp * 2] - 0.5f, yi = p.keypoints[kp * 2 + 1] - 0.5f;
+    float gx, gy, ix, iy;
+    if (p.mode == 0) {  // legacy: shifted grid, align_corners=True
+        gx = __fadd_rn(__fsub_rn(xi, 4.f), 0.5f);
+        gy = __fadd_rn(__fsub_rn(yi, 4.f), 0.5f);
+    } else if (p.mode == 1) {
+        gx = xi; gy = yi;
+    } else {
+        gx = __fadd_rn(xi, 0.5f); gy = __fadd_rn(yi, 0.5f);
+    }
+    gx = __fsub_rn(__fmul_rn(__fdiv_rn(gx, divx), 2.f), 1.f);
+    gy = __fsub_rn(__fmul_rn(__fdiv_rn(gy, divy), 2.f), 1.f);
+    if (p.mode == 0) {
+        ix = __fmul_rn(__fadd_rn(gx, 1.f), (float)(p.wc - 1) / 2.f);
+        iy = __fmul_rn(__fadd_rn(gy, 1.f), (float)(p.hc - 1) / 2.f);
+    } else {
+        ix = __fsub_rn(__fmul_rn(__fadd_rn(gx, 1.f), (float)p.wc / 2.f), 0.5f);
+        iy = __fsub_rn(__fmul_rn(__fadd_rn(gy, 1.f), (float)p.hc / 2.f), 0.5f);
+    }
+    const float xw = floorf(ix), yn = floorf(iy);
+    const float w = __fsub_rn(ix, xw), e = __fsub_rn(1.f, w), nn = __fsub_rn(iy, yn), s = __fsub_rn(1.f, nn);
+    const float wnw = __fmul_rn(s, e), wne = __fmul_rn(s, w), wsw = __fmul_rn(nn, e), wse = __fmul_rn(nn, w);
+    const int x0 = (int)xw, y0 = (int)yn;
+    const float* dense = p.dense + (long long)b * p.hc * p.wc * 256;
+    auto corner = [&](int yy, int xx) -> f32x4 {
+        if (yy < 0 || yy >= p.hc || xx < 0 || xx >= p.wc) return f32x4{0.f, 0.f, 0.f, 0.f};
+        return *reinterpret_cast<const f32x4*>(dense + ((long long)yy * p.wc + xx) * 256 + lane * 4);
+    };
+    const f32x4 vnw = corner(y0, x0), vne = corner(y0, x0 + 1), vsw = corner(y0 + 1, x0), vse = corner(y0 + 1, x0 + 1);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = __fadd_rn(__fadd_rn(__fadd_rn(__fmul_rn(vnw[j], wnw), __fmul_rn(vne[j], wne)), __fmul_rn(vsw[j], wsw)), __fmul_rn(vse[j], wse));
+    float ss = o.x * o.x + o.y * o.y + o.z * o.z + o.w * o.w;
+    ss = wave_sum(ss);
+    const float d = fmaxf(sqrtf(ss), 1e-12f);
+    o.x /= d; o.y /= d; o.z /= d; o.w /= d;
+    *reinterpret_cast<f32x4*>(p.desc + kp * 256 + lane * 4) = o;
+}
+
+}  // namespace
+
+void launch_softmax_d2s(const float* logits, int ld, int B, int hc, int wc, float* heat, hipStream_t s) {
+    const long long cells = (long long)B * hc * wc;
+    hipLaunchKernelGGL(softmax_d2s_kernel, dim3((unsigned)((cells + 3) / 4)), dim3(256), 0, s, logits, ld, B, hc, wc, heat);
+}
+
+void launch_l2norm_rows(float* x, long long rows, int dim, hipStream_t s) {
+    hipLaunchKernelGGL(l2norm_rows_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, dim);
+}
+
+void launch_nhwc_to_nchw(const float* in, float* out, int B, int HW, int C, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((HW + 31) / 32, (C + 31) / 32, B), dim3(256), 0, s, in, out, HW, C);
+}
+void launch_nchw_to_nhwc(const float* in, float* out, int B, int HW, int C, hipStream_t s) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((C + 31) / 32, (HW + 31) / 32, B), dim3(256), 0, s, in, out, C, HW);
+}
+
+void launch_detect(const DetectArgs& a, hipStream_t s) {
+    hipMemsetAsync(a.counts, 0, sizeof(int) * a.B, s);
+    dim3 grid((a.Ws + NMS_TILE - 1) / NMS_TILE, (a.Hs + NMS_TILE - 1) / NMS_TILE, a.B);
+    hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(select_kernel, dim3(a.B), dim3(SEL_THREADS), 0, s, a);
+}
+
+void launch_sample(const SampleArgs& a, hipStream_t s) {
+    float divx, divy;
+    if (a.mode == 0) {  // python double arithmetic then fp32, as torch.tensor([...]) does
+        divx = (float)((double)a.wc * 8 - 4.0 - 0.5);
+        divy = (float)((double)a.hc * 8 - 4.0 - 0.5);
+    } else {
+        divx = (float)a.wc * 8.f;
+        divy = (float)a.hc * 8.f;
+    }
+    const long long n = (long long)a.B * a.K;
+    hipLaunchKernelGGL(sample_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, a, divx, divy);
+}

@@ -1,0 +1,226 @@
+"""ctypes binding of libmatchglue.so (include/matchglue.h).
+
+This is the only place the product touches native code.  There is NO fallback: if the shared
+library is missing or a call fails, a RuntimeError is raised -- the product path never routes
+through PyTorch ops or the CPU oracle.
+"""
+import ctypes
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+
+import torch
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libmatchglue.so")
+
+MG_SP_MAGICLEAP, MG_SP_OPEN = 0, 1
+MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN = 0, 1, 2
+
+# every symbol include/matchglue.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_weight", "mg_weights_ready",
+    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_debug_request", "mg_debug_read",
+    "mg_profile_enable", "mg_profile_read", "mg_test_linear",
+]
+
+
+class SpConf(Structure):
+    _fields_ = [
+        ("variant", c_int32),
+        ("nms_radius", c_int32),
+        ("remove_borders", c_int32),
+        ("max_num_keypoints", c_int32),
+        ("sampling", c_int32),
+        ("detection_threshold", c_float),
+    ]
+
+
+class LgConf(Structure):
+    _fields_ = [("n_layers", c_int32), ("num_heads", c_int32), ("filter_threshold", c_float)]
+
+
+_lib = None
+
+
+def lib():
+    """Load the shared library once; fail loudly when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libmatchglue.so not found at {LIB_PATH}: build it with `python glue-factory_amd/build.py` "
+            "(or __graft_entry__.build()). There is no CPU/PyTorch fallback for this path."
+        )
+    L = ctypes.CDLL(LIB_PATH)
+    L.mg_last_error.restype = c_char_p
+    L.mg_create.argtypes = [c_int, POINTER(c_void_p)]
+    L.mg_destroy.argtypes = [c_void_p]
+    L.mg_set_weight.argtypes = [c_void_p, c_int, c_char_p, c_void_p, POINTER(c_int64), c_int]
+    L.mg_weights_ready.argtypes = [c_void_p, c_int, c_int]
+    L.mg_sp_forward.argtypes = [c_void_p, POINTER(SpConf), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                                c_void_p, c_void_p, c_void_p, c_void_p, c_void_p]
+    L.mg_sp_detect.argtypes = [c_void_p, POINTER(SpConf), c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p]
+    L.mg_sp_sample.argtypes = [c_void_p, POINTER(SpConf), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.mg_lg_forward.argtypes = [c_void_p, POINTER(LgConf)] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 8
+    L.mg_debug_request.argtypes = [c_void_p, c_char_p]
+    L.mg_debug_read.argtypes = [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]
+    L.mg_profile_enable.argtypes = [c_void_p, c_int]
+    L.mg_profile_read.argtypes = [c_void_p, c_void_p, POINTER(c_float), c_int]
+    L.mg_test_linear.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != 0:
+        raise RuntimeError(f"libmatchglue error {rc}: {lib().mg_last_error().decode()}")
+
+
+def _ptr(t):
+    return None if t is None else c_void_p(t.data_ptr())
+
+
+def _stream(device):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)
+
+
+def _f32(t, device):
+    return t.to(device=device, dtype=torch.float32).contiguous()
+
+
+class Engine:
+    """One native handle (weights + workspace) bound to one HIP device."""
+
+    def __init__(self, device):
+        device = torch.device(device)
+        if device.type != "cuda":
+            raise RuntimeError(
+                f"the MI355X path runs on a HIP device only (got '{device}'); there is no CPU fallback -- "
+                "move the module and its inputs to 'cuda'"
+            )
+        self.device = torch.device("cuda", device.index if device.index is not None else torch.cuda.current_device())
+        self._h = c_void_p()
+        _check(lib().mg_create(self.device.index, ctypes.byref(self._h)))
+        self._keep = []
+
+    def close(self):
+        if self._h:
+            lib().mg_destroy(self._h)
+            self._h = c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ---------------------------------------------------------------------------------
+    def set_weights(self, which, state_dict, variant_or_layers):
+        for k, v in state_dict.items():
+            if not torch.is_tensor(v) or not v.dtype.is_floating_point:
+                continue
+            t = v.detach().to("cpu", torch.float32).contiguous()
+            shape = (c_int64 * max(t.dim(), 1))(*t.shape)
+            _check(lib().mg_set_weight(self._h, which, k.encode(), c_void_p(t.data_ptr()), shape, t.dim()))
+        _check(lib().mg_weights_ready(self._h, which, variant_or_layers))
+
+    # -- SuperPoint ------------------------------------------------------------------------------
+    def sp_forward(self, conf, image, image_size=None, want_heatmap=False, want_dense=False):
+        dev = self.device
+        image = _f32(image, dev)
+        B, C, H, W = image.shape
+        K = conf.max_num_keypoints
+        isz = None if image_size is None else _f32(image_size, dev)
+        kp = torch.empty(B, K, 2, device=dev)
+        sc = torch.empty(B, K, device=dev)
+        ds = torch.empty(B, K, 256, device=dev)
+        nv = torch.empty(B, dtype=torch.int32, device=dev)
+        hc, wc = H // 8, W // 8
+        heat = torch.empty(B, hc * 8, wc * 8, device=dev) if want_heatmap else None
+        dense = torch.empty(B, 256, hc, wc, device=dev) if want_dense else None
+        _check(lib().mg_sp_forward(self._h, ctypes.byref(conf), _ptr(image), B, C, H, W, _ptr(isz), _ptr(kp), _ptr(sc), _ptr(ds),
+                                   _ptr(nv), _ptr(heat), _ptr(dense), _stream(dev)))
+        return kp, sc, ds, nv, heat, dense
+
+    def sp_detect(self, conf, heatmap, image_size=None, want_nms=False):
+        dev = self.device
+        heatmap = _f32(heatmap, dev)
+        B, Hs, Ws = heatmap.shape
+        K = conf.max_num_keypoints
+        isz = None if image_size is None else _f32(image_size, dev)
+        kp = torch.empty(B, K, 2, device=dev)
+        sc = torch.empty(B, K, device=dev)
+        nv = torch.empty(B, dtype=torch.int32, device=dev)
+        nms = torch.empty(B, Hs, Ws, device=dev) if want_nms else None
+        _check(lib().mg_sp_detect(self._h, ctypes.byref(conf), _ptr(heatmap), B, Hs, Ws, _ptr(isz), _ptr(kp), _ptr(sc), _ptr(nv),
+                                  _ptr(nms), _stream(dev)))
+        return kp, sc, nv, nms
+
+    def sp_sample(self, conf, keypoints, dense_nchw):
+        dev = self.device
+        keypoints = _f32(keypoints, dev)
+        dense_nchw = _f32(dense_nchw, dev)
+        B, K, _ = keypoints.shape
+        _, Cc, hc, wc = dense_nchw.shape
+        assert Cc == 256
+        out = torch.empty(B, K, 256, device=dev)
+        _check(lib().mg_sp_sample(self._h, ctypes.byref(conf), _ptr(keypoints), _ptr(dense_nchw), B, K, hc, wc, _ptr(out), _stream(dev)))
+        return out
+
+    # -- LightGlue -------------------------------------------------------------------------------
+    def lg_forward(self, conf, k0, k1, d0, d1, size0=None, size1=None, want_log_assignment=True, want_ref=True):
+        dev = self.device
+        k0, k1, d0, d1 = (_f32(t, dev) for t in (k0, k1, d0, d1))
+        B, M, _ = k0.shape
+        N = k1.shape[1]
+        if d0.shape != (B, M, 256) or d1.shape != (B, N, 256):
+            raise RuntimeError(f"descriptors must be (B,K,256); got {tuple(d0.shape)} / {tuple(d1.shape)}")
+        s0 = None if size0 is None else _f32(size0, dev).reshape(-1, 2).expand(B, 2).contiguous()
+        s1 = None if size1 is None else _f32(size1, dev).reshape(-1, 2).expand(B, 2).contiguous()
+        m0 = torch.empty(B, M, dtype=torch.int64, device=dev)
+        m1 = torch.empty(B, N, dtype=torch.int64, device=dev)
+        ms0 = torch.empty(B, M, device=dev)
+        ms1 = torch.empty(B, N, device=dev)
+        la = torch.empty(B, M + 1, N + 1, device=dev) if want_log_assignment else None
+        r0 = torch.empty(B, M, 256, device=dev) if want_ref else None
+        r1 = torch.empty(B, N, 256, device=dev) if want_ref else None
+        _check(lib().mg_lg_forward(self._h, ctypes.byref(conf), _ptr(k0), _ptr(k1), _ptr(d0), _ptr(d1), _ptr(s0), _ptr(s1), B, M, N,
+                                   _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1), _ptr(la), _ptr(r0), _ptr(r1), _stream(dev)))
+        return m0, m1, ms0, ms1, la, r0, r1
+
+    # -- introspection ---------------------------------------------------------------------------
+    def debug_request(self, tap):
+        _check(lib().mg_debug_request(self._h, tap.encode()))
+
+    def debug_read(self, tap, numel):
+        out = torch.empty(numel, device=self.device)
+        n = c_size_t(0)
+        _check(lib().mg_debug_read(self._h, tap.encode(), _ptr(out), numel, ctypes.byref(n), _stream(self.device)))
+        return out[: n.value]
+
+    def profile_enable(self, on=True):
+        _check(lib().mg_profile_enable(self._h, 1 if on else 0))
+
+    def profile_read(self, cap=4096):
+        names = ctypes.create_string_buffer(48 * cap)
+        ms = (c_float * cap)()
+        n = lib().mg_profile_read(self._h, names, ms, cap)
+        if n < 0:
+            _check(n)
+        out = []
+        for i in range(min(n, cap)):
+            out.append((names.raw[48 * i: 48 * (i + 1)].split(b"\0", 1)[0].decode(), float(ms[i])))
+        return out
+
+    def test_linear(self, A, W, bias=None):
+        A = _f32(A, self.device)
+        Wc = W.detach().to("cpu", torch.float32).contiguous()
+        bc = None if bias is None else bias.detach().to("cpu", torch.float32).contiguous()
+        M, K = A.shape
+        N = Wc.shape[0]
+        C = torch.empty(M, N, device=self.device)
+        _check(lib().mg_test_linear(self._h, _ptr(A), c_void_p(Wc.data_ptr()), None if bc is None else c_void_p(bc.data_ptr()), M, N, K,
+                                    _ptr(C), _stream(self.device)))
+        return C

@@ -1,0 +1,71 @@
+"""Data-parallel sharding of image pairs over the GPUs of one node.
+
+Pairs are independent units (no exchange inside the path), so each rank runs the whole
+SuperPoint + LightGlue forward on a contiguous block of B/G pairs with replicated weights; the only
+collective is ONE all-gather of the fixed-shape match outputs (RCCL over xGMI when the process group
+backend is "nccl", gloo in the CPU tests).  Indices travel as int32 and are widened to the
+reference's int64 on return; descriptors are not gathered (134 MB/rank at config 3) unless asked.
+
+The reference has no inference-time collective (its only distributed code is DDP training,
+gluefactory/train.py:235-257); this is the MI355X-native addition named by BASELINE.json.
+"""
+import torch
+import torch.distributed as dist
+
+GATHER_KEYS = ("matches0", "matches1", "matching_scores0", "matching_scores1")
+OPTIONAL_KEYS = ("keypoints0", "keypoints1", "keypoint_scores0", "keypoint_scores1")
+
+
+def shard_range(num_pairs, rank, world_size):
+    """Contiguous block of pairs owned by `rank` (sizes differ by at most one)."""
+    base, extra = divmod(num_pairs, world_size)
+    start = rank * base + min(rank, extra)
+    return start, start + base + (1 if rank < extra else 0)
+
+
+def shard_batch(data, rank, world_size):
+    """Slice every batched tensor of a (possibly nested) two-view data dict to this rank's pairs."""
+    n = data["view0"]["image"].shape[0]
+    lo, hi = shard_range(n, rank, world_size)
+
+    def cut(x):
+        if isinstance(x, dict):
+            return {k: cut(v) for k, v in x.items()}
+        if torch.is_tensor(x) and x.dim() > 0 and x.shape[0] == n:
+            return x[lo:hi]
+        return x
+
+    return cut(data)
+
+
+def all_gather_matches(pred, group=None, with_keypoints=False):
+    """All-gather the match outputs of every rank (equal shard sizes) -> full-batch tensors on all ranks.
+
+    One packed buffer per rank -> a single all_gather_into_tensor call.
+    """
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return {k: pred[k] for k in GATHER_KEYS + (OPTIONAL_KEYS if with_keypoints else ()) if k in pred}
+    world = dist.get_world_size(group)
+    keys = [k for k in GATHER_KEYS + (OPTIONAL_KEYS if with_keypoints else ()) if k in pred]
+    parts, meta = [], []
+    for k in keys:
+        t = pred[k]
+        if t.dtype == torch.int64:
+            w = t.to(torch.int32).view(torch.float32) if t.is_contiguous() else t.contiguous().to(torch.int32).view(torch.float32)
+        else:
+            w = t.float()
+        meta.append((k, t.shape, t.dtype))
+        parts.append(w.reshape(t.shape[0], -1))
+    packed = torch.cat(parts, 1).contiguous()  # (b_local, F) fp32 words
+    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out.view(-1, packed.shape[1]), packed, group=group)
+    out = out.view(world * packed.shape[0], -1)
+    res, col = {}, 0
+    for k, shape, dtype in meta:
+        f = int(torch.tensor(shape[1:]).prod()) if len(shape) > 1 else 1
+        chunk = out[:, col: col + f]
+        col += f
+        if dtype == torch.int64:
+            chunk = chunk.contiguous().view(torch.int32).to(torch.int64)
+        res[k] = chunk.reshape((out.shape[0],) + tuple(shape[1:]))
+    return res

@@ -1,0 +1,137 @@
+/*
+ * matchglue.h -- C ABI of the MI355X-native SuperPoint + LightGlue forward path.
+ *
+ * This is the drop-in boundary for the one hot path of glue-factory's evaluation pipeline:
+ *   extractor  gluefactory_nonfree/superpoint.py:202-350  (SuperPoint._forward, MagicLeap layout)
+ *              gluefactory/models/extractors/superpoint_open.py:123-217 (open variant)
+ *   matcher    gluefactory/models/matchers/lightglue.py:399-525 (LightGlue.forward)
+ * The reference reaches that path through Python `nn.Module.__call__` on `BaseModel` subclasses
+ * (gluefactory/models/base_model.py:103-114); it has no FFI of its own, so the entry points below
+ * are what a binding for that path would call (see INTEGRATION.md for the ctypes stub).
+ *
+ * Conventions
+ *   - plain C: opaque handle, raw pointers, sizes; no C++ exceptions cross the boundary.
+ *   - every function returns 0 on success or a negative mg_status; mg_last_error() gives text.
+ *   - all tensor pointers are DEVICE pointers owned by the caller unless marked "host".
+ *   - launches are asynchronous on the `stream` argument (a hipStream_t passed as void*).
+ *   - one handle per device; a handle is not re-entrant.
+ *   - workspace and weights are owned by the handle (hipMalloc at create / first use of a shape).
+ */
+#ifndef MATCHGLUE_H
+#define MATCHGLUE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mg_context* mg_handle;
+
+enum mg_status {
+    MG_OK = 0,
+    MG_ERR_ARG = -1,      /* bad argument / unsupported shape */
+    MG_ERR_HIP = -2,      /* HIP runtime error */
+    MG_ERR_WEIGHTS = -3,  /* missing or mis-shaped weight tensor */
+    MG_ERR_STATE = -4     /* call order (e.g. forward before weights are complete) */
+};
+
+enum mg_sp_variant { MG_SP_MAGICLEAP = 0, MG_SP_OPEN = 1 };
+/* descriptor sampling conventions: superpoint.py:117-133 (legacy), :138-149 (fixed),
+ * superpoint_open.py:20-31 (open) */
+enum mg_sampling { MG_SAMPLE_LEGACY = 0, MG_SAMPLE_FIXED = 1, MG_SAMPLE_OPEN = 2 };
+
+/* Extractor configuration == the conf keys of superpoint.py:153-169 that the sparse path reads. */
+typedef struct mg_sp_conf {
+    int32_t variant;            /* mg_sp_variant */
+    int32_t nms_radius;         /* 0..4 */
+    int32_t remove_borders;     /* pixels, 0 = off */
+    int32_t max_num_keypoints;  /* 1..4096 */
+    int32_t sampling;           /* mg_sampling */
+    float detection_threshold;
+} mg_sp_conf;
+
+/* Matcher configuration == lightglue.py:307-327 (depth/width adaptivity is dead in the reference). */
+typedef struct mg_lg_conf {
+    int32_t n_layers;   /* 9 */
+    int32_t num_heads;  /* 4 (head dim 64, descriptor dim 256) */
+    float filter_threshold;
+} mg_lg_conf;
+
+/* -- lifetime ------------------------------------------------------------------------------- */
+int mg_create(int device, mg_handle* out);
+int mg_destroy(mg_handle h);
+const char* mg_last_error(void);
+/* ABI version of this header (bumped on any signature change). */
+int mg_abi_version(void);
+
+/* -- weights ---------------------------------------------------------------------------------
+ * Upload one tensor of a reference state_dict, addressed by its reference key name
+ * ("conv1a.weight", "backbone.0.0.bn.running_var", "transformers.3.self_attn.Wqkv.weight", ...).
+ * `data` is a HOST pointer to contiguous fp32 in the reference's own layout (OIHW / [out][in]);
+ * the library re-tiles it for the kernels.  `which` selects the model: 0 = SuperPoint, 1 = LightGlue.
+ * mg_weights_ready() re-tiles and uploads; it returns 0 once every tensor the model needs has
+ * arrived.  `variant_or_layers` is the mg_sp_variant for which == 0 and n_layers for which == 1. */
+int mg_set_weight(mg_handle h, int which, const char* key, const float* data, const int64_t* shape, int ndim);
+int mg_weights_ready(mg_handle h, int which, int variant_or_layers);
+
+/* -- SuperPoint -------------------------------------------------------------------------------
+ * image        (B,C,H,W) fp32 in [0,1], C in {1,3}, NCHW as the reference takes it
+ * image_size   (B,2) fp32 (w,h) or NULL  -- superpoint.py:247-251 (MagicLeap variant only)
+ * keypoints    (B,K,2) fp32 (x,y)+0.5     K = conf.max_num_keypoints
+ * scores       (B,K)   fp32
+ * descriptors  (B,K,256) fp32, L2-normalised
+ * num_valid    (B) int32: min(#candidates, K); rows >= num_valid are zero-filled
+ * heatmap      optional (B,8*(H/8),8*(W/8)) fp32 dense scores before NMS   (NULL to skip)
+ * dense_desc   optional (B,256,H/8,W/8) fp32 NCHW normalised descriptors    (NULL to skip)
+ */
+int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B, int C, int H, int W,
+                  const float* image_size, float* keypoints, float* scores, float* descriptors,
+                  int32_t* num_valid, float* heatmap, float* dense_desc, void* stream);
+
+/* Stage entry points (same kernels, used by the stage-wise parity tests and by callers that
+ * already hold a dense map):
+ *   mg_sp_detect : heatmap (B,Hs,Ws) -> NMS + border + threshold + top-k  (superpoint.py:241-302)
+ *                  nms_out optional (B,Hs,Ws): the NMS'd, border-masked map the reference thresholds
+ *   mg_sp_sample : integer keypoints + dense NCHW descriptors -> (B,K,256)  (superpoint.py:323-339)
+ */
+int mg_sp_detect(mg_handle h, const mg_sp_conf* conf, const float* heatmap, int B, int Hs, int Ws,
+                 const float* image_size, float* keypoints, float* scores, int32_t* num_valid,
+                 float* nms_out, void* stream);
+int mg_sp_sample(mg_handle h, const mg_sp_conf* conf, const float* keypoints, const float* dense_nchw,
+                 int B, int K, int Hc, int Wc, float* descriptors, void* stream);
+
+/* -- LightGlue --------------------------------------------------------------------------------
+ * kpts0 (B,M,2), kpts1 (B,N,2) fp32 pixel coords; desc0 (B,M,256), desc1 (B,N,256)
+ * size0/size1  (B,2) fp32 (w,h) or NULL (then the keypoint extent is used, lightglue.py:25-26)
+ * matches0 (B,M) int64, matches1 (B,N) int64 (-1 = unmatched); mscores0/1 fp32
+ * log_assignment optional (B,M+1,N+1) fp32; ref_desc0/1 optional (B,M,256)/(B,N,256) = last layer
+ */
+int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const float* kpts1,
+                  const float* desc0, const float* desc1, const float* size0, const float* size1,
+                  int B, int M, int N, int64_t* matches0, int64_t* matches1, float* mscores0,
+                  float* mscores1, float* log_assignment, float* ref_desc0, float* ref_desc1, void* stream);
+
+/* -- introspection ----------------------------------------------------------------------------
+ * Copy a named internal buffer of the LAST forward into `dst` (device, fp32), for stage-wise
+ * parity tests: "lg.enc" (tokens,64), "lg.self<i>" / "lg.layer<i>" (tokens,256) descriptors after
+ * the self / cross block of layer i (both images, image-0 rows first).  Returns element count in
+ * *count.  Only taps requested beforehand with mg_debug_request() are kept.                    */
+int mg_debug_request(mg_handle h, const char* tap);
+int mg_debug_read(mg_handle h, const char* tap, float* dst, size_t capacity, size_t* count, void* stream);
+
+/* Timing of the dominant kernels of the last forward, measured with HIP events on `stream`
+ * when enabled: mg_profile_enable(h,1); after a forward + stream sync, mg_profile_read() fills
+ * names/ms for up to `cap` entries and returns the number available.                          */
+int mg_profile_enable(mg_handle h, int on);
+int mg_profile_read(mg_handle h, char (*names)[48], float* ms, int cap);
+
+/* Stand-alone GEMM self-test entry: C[M,N] = A[M,K] * W[N,K]^T + bias (fp32-in MFMA core).     */
+int mg_test_linear(mg_handle h, const float* A, const float* W_host, const float* bias_host, int M, int N,
+                   int K, float* C, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MATCHGLUE_H */

@@ -1,0 +1,146 @@
+"""Host-side contract tests (CPU): conf handling, registry, weight naming, no-fallback, sharding + all-gather."""
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import sp_lg_oracle as O
+
+
+def test_conf_merge_and_extra_keys():
+    from gluefactory_amd import get_model
+
+    SP = get_model("gluefactory_amd.superpoint")
+    # the reference passes name/trainable/... through (base_model.py:54-59, two_view_pipeline.py:46)
+    m = SP({"name": "gluefactory_nonfree.superpoint", "trainable": False, "max_num_keypoints": 1024, "nms_radius": 3, "timeit": False})
+    assert m.conf.nms_radius == 3 and m.conf.remove_borders == 4 and m.conf.legacy_sampling is True
+    with pytest.raises(AttributeError):
+        m.conf.no_such_key
+    with pytest.raises(TypeError):
+        m.conf.nms_radius = 5
+    nc = m._native_conf()
+    assert (nc.nms_radius, nc.max_num_keypoints, nc.sampling) == (3, 1024, 0)
+    SPO = get_model("superpoint_open")
+    mo = SPO({"max_num_keypoints": None})
+    assert mo._native_conf().sampling == 2 and mo._native_conf().max_num_keypoints == 4096
+
+
+def test_registry_resolves_reference_names():
+    from gluefactory_amd.two_view_pipeline import TwoViewPipeline
+
+    p = TwoViewPipeline({
+        "extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": 512},
+        "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "depth_confidence": -1, "width_confidence": -1},
+    })
+    assert type(p.extractor).__module__ == "gluefactory_amd.superpoint"
+    assert type(p.matcher).__module__ == "gluefactory_amd.lightglue"
+    assert not p.is_initialized()  # eval/io.py:92-96 rejects models without weights
+    p.extractor.load_state_dict(O.make_sp_weights(0))
+    p.matcher.load_state_dict(O.make_lg_weights(0))
+    assert p.is_initialized()
+    with pytest.raises(NotImplementedError):
+        TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint"}, "solver": {"name": "homography_est"}})
+
+
+def test_state_dict_uses_reference_key_names():
+    from gluefactory_amd import get_model
+
+    lg = get_model("lightglue")({})
+    W = O.make_lg_weights(3)
+    legacy = {k.replace("transformers.2.self_attn", "self_attn.2").replace("transformers.2.cross_attn", "cross_attn.2"): v for k, v in W.items()}
+    lg.load_state_dict(legacy)  # lightglue.py:378-385 legacy rename
+    sd = lg.state_dict()
+    assert set(sd) == set(W)
+    assert torch.equal(sd["transformers.2.self_attn.Wqkv.weight"], W["transformers.2.self_attn.Wqkv.weight"])
+    sp = get_model("superpoint")({})
+    sp.load_state_dict({**O.make_sp_weights(0), "unrelated.weight": torch.zeros(1)})
+    assert set(sp.state_dict()) == set(O.make_sp_weights(0))
+
+
+def test_missing_keys_assert_like_reference():
+    from gluefactory_amd import get_model
+
+    lg = get_model("lightglue")({})
+    lg.load_state_dict(O.make_lg_weights(0))
+    with pytest.raises(AssertionError, match="Missing key descriptors1"):
+        lg({"keypoints0": 0, "keypoints1": 0, "descriptors0": 0})
+
+
+def test_no_cpu_fallback():
+    from gluefactory_amd import get_model
+
+    sp = get_model("superpoint")({"max_num_keypoints": 64})
+    sp.load_state_dict(O.make_sp_weights(0))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        sp({"image": torch.zeros(1, 1, 64, 64)})
+    lg = get_model("lightglue")({})
+    with pytest.raises(RuntimeError):
+        lg({"keypoints0": torch.zeros(1, 4, 2), "keypoints1": torch.zeros(1, 4, 2), "descriptors0": torch.zeros(1, 4, 256), "descriptors1": torch.zeros(1, 4, 256)})
+
+
+def test_rejected_options():
+    from gluefactory_amd import get_model
+
+    with pytest.raises(NotImplementedError):
+        get_model("lightglue")({"depth_confidence": 0.95})
+    with pytest.raises(NotImplementedError):
+        get_model("superpoint")({"refinement_radius": 2})
+    with pytest.raises(FileNotFoundError):
+        get_model("superpoint")({"weights": "/nonexistent/superpoint_v1.pth"})
+
+
+def test_shard_ranges_cover_batch():
+    from gluefactory_amd.parallel import shard_batch, shard_range
+
+    for n in (1, 7, 32, 256):
+        for w in (1, 2, 3, 8):
+            spans = [shard_range(n, r, w) for r in range(w)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+    data = {"view0": {"image": torch.arange(8.0).view(8, 1, 1, 1), "image_size": torch.ones(8, 2)}, "view1": {"image": torch.zeros(8, 1, 1, 1)}, "name": "x"}
+    s = shard_batch(data, 1, 4)
+    assert s["view0"]["image"].flatten().tolist() == [2.0, 3.0] and s["view0"]["image_size"].shape == (2, 2) and s["name"] == "x"
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _gather_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from gluefactory_amd.parallel import all_gather_matches, shard_range
+
+    g = torch.Generator().manual_seed(0)
+    full = {
+        "matches0": torch.randint(-1, 50, (4, 9), generator=g),
+        "matches1": torch.randint(-1, 50, (4, 7), generator=g),
+        "matching_scores0": torch.rand(4, 9, generator=g),
+        "matching_scores1": torch.rand(4, 7, generator=g),
+        "keypoints0": torch.rand(4, 9, 2, generator=g),
+    }
+    lo, hi = shard_range(4, rank, world)
+    local = {k: v[lo:hi] for k, v in full.items()}
+    got = all_gather_matches(local, with_keypoints=True)
+    ok = all(torch.equal(got[k], full[k]) and got[k].dtype == full[k].dtype for k in full)
+    out[rank] = ok
+    dist.destroy_process_group()
+
+
+def test_all_gather_matches_world2_gloo():
+    """N>1 path: each rank holds B/2 pairs; one packed all-gather reproduces the full-batch outputs."""
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    os.environ["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "glue-factory_amd"), os.environ.get("PYTHONPATH", "")])
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_gather_worker, args=(2, _free_port(), out), nprocs=2, join=True)
+    assert out[0] and out[1]
