@@ -1,0 +1,197 @@
+#!/usr/bin/env python3
+"""Headline benchmark: image-pairs/sec of SuperPoint(view0) + SuperPoint(view1) + LightGlue forward.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...
+
+Workload = BASELINE.json config 2: 640x480 gray images, 1024 keypoints, 32 pairs per GPU per step
+(weak scaling: every rank runs its own 32 pairs; the only collective is one RCCL all-gather of the
+match outputs per step).  Inputs are synthetic (seeded smooth noise) and resident in HBM before the
+timed region; weights are seeded (there are no checkpoints offline).  One "step" = one pass of the
+hot path over one batch: extractor on 2B images, matcher on B pairs, all-gather.
+
+Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, HIP-event
+timed inside the timed region) and, at N == 1, `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "glue-factory_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+H, W, K, PAIRS = 480, 640, 1024, 32
+PEAK_F32_MFMA = 157.3  # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32 rate)
+
+
+def synthetic_images(n, seed):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.rand(n, 1, H + 8, W + 8, generator=g)
+    x = torch.nn.functional.avg_pool2d(x, 5, 1)[:, :, 2:H + 2, 2:W + 2]
+    x = x - x.amin(dim=(2, 3), keepdim=True)
+    return (x / x.amax(dim=(2, 3), keepdim=True)).contiguous()
+
+
+def algorithmic_flops(B):
+    """Algorithmic FLOPs per launch of every profiled kernel family (SURVEY.md section 8d formulae);
+    B = pairs per step; SuperPoint runs on 2B images."""
+    n = 2 * B
+    hw = [H * W, H * W // 4, H * W // 16, H * W // 64]
+    conv = lambda ci, co, px: 2.0 * 9 * ci * co * px * n
+    T = (K + K) * B  # tokens per step
+    lin = lambda i, o: 2.0 * T * i * o
+    f = {
+        "sp.conv1a": conv(1, 64, hw[0]), "sp.conv1b": conv(64, 64, hw[0]),
+        "sp.conv2a": conv(64, 64, hw[1]), "sp.conv2b": conv(64, 64, hw[1]),
+        "sp.conv3a": conv(64, 128, hw[2]), "sp.conv3b": conv(128, 128, hw[2]),
+        "sp.conv4a": conv(128, 128, hw[3]), "sp.conv4b": conv(128, 128, hw[3]),
+        "sp.convPa": conv(128, 256, hw[3]), "sp.convDa": conv(128, 256, hw[3]),
+        "sp.convPb": 2.0 * 256 * 65 * hw[3] * n, "sp.convDb": 2.0 * 256 * 256 * hw[3] * n,
+        "lg.gemm.qkv": lin(256, 768), "lg.gemm.qkv_cross": lin(256, 512), "lg.gemm.out": lin(256, 256),
+        "lg.gemm.ffn0": lin(512, 512), "lg.gemm.ffn3": lin(512, 256), "lg.gemm.final_proj": lin(256, 256),
+        "lg.gemm.sim": 2.0 * B * K * K * 256,
+        # attention contractions: 2*h*Nq*Nk*dh each; self = QK^T + PV on both images;
+        # cross = one shared similarity + two PV products (the reference computes sim once, lightglue.py:201)
+        "lg.attn.self": 2 * (2.0 * 4 * K * K * 64) * 2 * B,
+        "lg.attn.cross": 3 * (2.0 * 4 * K * K * 64) * B,
+    }
+    return f
+
+
+def cpu_baseline(pairs=2):
+    """The CPU oracle (oracle/sp_lg_oracle.py, a restatement of the reference) on a bounded sample."""
+    from oracle import sp_lg_oracle as O
+
+    torch.set_grad_enabled(False)
+    W_sp, W_lg = O.make_sp_weights(0), O.make_lg_weights(7, final_gain=8.0, match_bias=2.0)
+    im = synthetic_images(2 * pairs, 123)
+    size = torch.tensor([[float(W), float(H)]])
+    spc = dict(nms_radius=3, detection_threshold=0.0, max_num_keypoints=K)
+    t0 = time.perf_counter()
+    for i in range(pairs):
+        data = {"view0": {"image": im[2 * i: 2 * i + 1], "image_size": size}, "view1": {"image": im[2 * i + 1: 2 * i + 2], "image_size": size}}
+        O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1))
+    dt = time.perf_counter() - t0
+    return {"value": pairs / dt, "unit": "pairs/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{pairs} pairs of the same workload (640x480, {K} kpts), batch 1, {dt:.1f} s of CPU time"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pairs", type=int, default=PAIRS, help="pairs per GPU per step")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    from gluefactory_amd.parallel import all_gather_matches
+    from gluefactory_amd.two_view_pipeline import TwoViewPipeline
+    from oracle import sp_lg_oracle as O  # seeded weight generators only
+
+    torch.set_grad_enabled(False)
+    B = args.pairs
+    pipe = TwoViewPipeline({
+        "extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": K, "nms_radius": 3,
+                      "detection_threshold": 0.0, "remove_borders": 4, "force_num_keypoints": True, "sync_free": True},
+        "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1},
+    }).eval()
+    pipe.extractor.load_state_dict(O.make_sp_weights(0))
+    pipe.matcher.load_state_dict(O.make_lg_weights(7, final_gain=8.0, match_bias=2.0))
+
+    im = synthetic_images(2 * B, 1000 + rank).to(dev)
+    size = torch.tensor([[float(W), float(H)]] * B, device=dev)
+    data = {"view0": {"image": im[:B], "image_size": size}, "view1": {"image": im[B:], "image_size": size}}
+
+    def step():
+        pred = pipe(data)
+        return all_gather_matches(pred) if world > 1 else pred
+
+    for _ in range(args.warmup):
+        out = step()
+    torch.cuda.synchronize()
+    # sanity outside the timed region: every image produced K keypoints, some matches exist
+    nvalid = int((out["matches0"] > -1).sum())
+
+    engines = [pipe.extractor.engine(dev), pipe.matcher.engine(dev)]
+    for e in engines:
+        e.profile_enable(True)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    prof = {}
+    for e in engines:
+        for name, ms in e.profile_read(cap=200 * max(args.steps, 1) + 64):
+            acc = prof.setdefault(name, [0.0, 0])
+            acc[0] += ms
+            acc[1] += 1
+        e.profile_enable(False)
+
+    if rank == 0:
+        flops = algorithmic_flops(B)
+        total_ms = sum(v[0] for v in prof.values()) or 1.0
+        dom = max((k for k in prof if k in flops), key=lambda k: prof[k][0])
+        avg_ms = prof[dom][0] / prof[dom][1]
+        achieved = flops[dom] / (avg_ms * 1e-3) / 1e12
+        kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps,
+                       "tflops": round(flops[k] * (v[1] / args.steps) / (v[0] / args.steps * 1e-3) / 1e12, 2) if k in flops else None}
+                   for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        res = {
+            "metric": "image-pairs/sec SP+LightGlue (VGA, 1024 kpts) at 1/2/4/8 MI355X",
+            "value": round(world * B * args.steps / dt, 3),
+            "unit": "pairs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(dt / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"SuperPoint + LightGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[1])",
+                       "pairs_per_gpu": B, "global_pairs": B * world, "parallelism": f"dp{world}", "matches_per_step_rank0": nvalid},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                         "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops[dom],
+                         "kernel_time_share": round(prof[dom][0] / total_ms, 4)},
+            "kernels": kernels,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(res), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -54,6 +54,29 @@ def test_mfma_gemm_random(engine, dev, M, N, K):
 
 
 # ------------------------------------------------------------------------------------------ detector
+def assert_topk_equivalent(got_xy, got_v, ref_yx, ref_v, score_map):
+    """Top-k equality up to exact score ties.
+
+    torch.topk's order among EQUAL scores (and which of them survive at rank k) is an artefact of its
+    partial sort, not a property of the algorithm (superpoint.py:83-87); this build breaks ties by the
+    lowest row-major index.  Scores must agree exactly as a sequence; positions must agree wherever the
+    score is unique, and as sets inside tie groups (a subset of the tied candidates at the rank-k edge).
+    """
+    assert torch.equal(got_v, ref_v)
+    ref_xy = torch.flip(ref_yx, [1])
+    same = (got_xy == ref_xy).all(-1)
+    if bool(same.all()):
+        return
+    for v in torch.unique(got_v[~same]).tolist():
+        mine = set(map(tuple, got_xy[got_v == v].tolist()))
+        theirs = set(map(tuple, ref_xy[ref_v == v].tolist()))
+        assert len(mine) == len(theirs) > 1, "positions differ at a unique score"
+        tied = set(map(tuple, torch.flip(torch.nonzero(score_map == v), [1]).tolist()))
+        assert mine <= tied and theirs <= tied
+        if v != float(got_v[-1]):
+            assert mine == theirs
+
+
 def test_nms_topk_golden(engine, golden):
     g = golden("nms_topk")
     s = g["scores"]
@@ -88,8 +111,7 @@ def test_detect_vs_oracle_fullsize(engine, shape, r, k):
     for b, (yx, v) in enumerate(sel):
         n = int(nv[b])
         assert n == len(v)
-        assert torch.equal(sc[b, :n].cpu(), v)
-        assert torch.equal((kp[b, :n].cpu() - 0.5).long(), torch.flip(yx, [1]))
+        assert_topk_equivalent((kp[b, :n].cpu() - 0.5).long(), sc[b, :n].cpu(), yx, v, ref_nms[b])
     # size-independent properties: sorted scores, all above threshold, unique locations, NMS idempotent
     if int(nv.min()) == k:
         assert torch.all(sc[:, :-1] >= sc[:, 1:])
@@ -253,7 +275,8 @@ def test_lightglue_vs_oracle_fullsize(dev, B, M, N):
     to = lambda x: {k: (to(v) if isinstance(v, dict) else v.to(dev)) for k, v in x.items()}
     p = m(to(data))
     torch.testing.assert_close(p["ref_descriptors0"][:, 0].cpu(), ref["ref_descriptors0"][:, 0], rtol=0, atol=ATOL)
-    torch.testing.assert_close(p["log_assignment"].cpu(), ref["log_assignment"], rtol=0, atol=5e-4)
+    # log-domain entries reach |x| ~ 1e2 here (fp32 ulp 8e-6..1.5e-5): relative + absolute tolerance
+    torch.testing.assert_close(p["log_assignment"].cpu(), ref["log_assignment"], rtol=2e-5, atol=ATOL)
     agree = (p["matches0"].cpu() == ref["matches0"]).float().mean().item()
     print(f"B{B} M{M} N{N}: matches0 agreement {agree:.5f}, matched {(ref['matches0'] > -1).float().mean().item():.3f}")
     assert agree > 0.999
