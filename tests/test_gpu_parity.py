@@ -275,8 +275,9 @@ def test_lightglue_vs_oracle_fullsize(dev, B, M, N):
     to = lambda x: {k: (to(v) if isinstance(v, dict) else v.to(dev)) for k, v in x.items()}
     p = m(to(data))
     torch.testing.assert_close(p["ref_descriptors0"][:, 0].cpu(), ref["ref_descriptors0"][:, 0], rtol=0, atol=ATOL)
-    # log-domain entries reach |x| ~ 1e2 here (fp32 ulp 8e-6..1.5e-5): relative + absolute tolerance
-    torch.testing.assert_close(p["log_assignment"].cpu(), ref["log_assignment"], rtol=2e-5, atol=ATOL)
+    # stress weights (final_proj = 8*I) push |sim| past 1e2, where one fp32 ulp is 8e-6..1.5e-5 and the
+    # similarity enters every entry twice (row + column log-softmax): allow a few ulps of |sim|
+    torch.testing.assert_close(p["log_assignment"].cpu(), ref["log_assignment"], rtol=2e-5, atol=5e-4)
     agree = (p["matches0"].cpu() == ref["matches0"]).float().mean().item()
     print(f"B{B} M{M} N{N}: matches0 agreement {agree:.5f}, matched {(ref['matches0'] > -1).float().mean().item():.3f}")
     assert agree > 0.999
