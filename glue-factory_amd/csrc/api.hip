@@ -68,6 +68,7 @@ struct DevBuf {
 struct ConvLayer {
     int Cin = 0, Cout = 0, CoutPad = 0;
     float *W = nullptr, *bias = nullptr, *ps = nullptr, *pt = nullptr;
+    float* Wh = nullptr;  // SH8 copy [Cin/16][9][CoutPad][64 B] for the f16x3 kernels
 };
 struct LinLayer {
     int N = 0, K = 0, Npad = 0;
@@ -89,6 +90,7 @@ struct ProfEntry {
 
 struct mg_context {
     int device = 0;
+    int precision = MG_PREC_F16X3;
     std::map<std::string, HostTensor> raw[2];
     std::vector<void*> owned;  // device allocations of prepared weights
 
@@ -191,6 +193,21 @@ int prep_conv3(mg_context* h, int which, const std::string& wkey, const std::str
             for (int tap = 0; tap < 9; ++tap)
                 t[(((size_t)(c >> 3) * 9 + tap) * L->CoutPad + n) * 8 + (c & 7)] = w->data[((size_t)n * Cin + c) * 9 + tap];
     if (int rc = upload(h, t, &L->W)) return rc;
+    // SH8 split-fp16 copy: [Cin/16][9][CoutPad][ (8 hi | 8 lo) x 2 groups ]
+    std::vector<float> sh((size_t)(Cin / 16) * 9 * L->CoutPad * 16, 0.f);
+    _Float16* hp = reinterpret_cast<_Float16*>(sh.data());
+    for (int n = 0; n < Cout; ++n)
+        for (int c = 0; c < Cin; ++c)
+            for (int tap = 0; tap < 9; ++tap) {
+                const float v = w->data[((size_t)n * Cin + c) * 9 + tap];
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const size_t row = ((size_t)(c >> 4) * 9 + tap) * L->CoutPad + n;  // 64-byte row = 32 halves
+                const int grp = (c >> 3) & 1, j = c & 7;
+                hp[row * 32 + grp * 16 + j] = hi;
+                hp[row * 32 + grp * 16 + 8 + j] = lo;
+            }
+    if (int rc = upload(h, sh, &L->Wh)) return rc;
     return upload(h, b->data, &L->bias);
 }
 
@@ -390,7 +407,7 @@ int run_detect(mg_context* h, const mg_sp_conf* conf, const float* heat, int B, 
     d.threshold = conf->detection_threshold;
     d.image_size = (conf->variant == MG_SP_MAGICLEAP) ? image_size : nullptr;
     d.cand = reinterpret_cast<unsigned long long*>(h->buf("sp.cand", (size_t)B * Hs * Ws * 2));
-    d.counts = reinterpret_cast<int*>(h->buf("sp.counts", (size_t)B));
+    d.counts = reinterpret_cast<int*>(h->buf("sp.counts", (size_t)B * 32));
     if (!d.cand || !d.counts) return fail(MG_ERR_HIP, "workspace allocation failed");
     d.nms_out = nms_out;
     d.keypoints = keypoints;
@@ -406,7 +423,7 @@ int run_detect(mg_context* h, const mg_sp_conf* conf, const float* heat, int B, 
 // ================================================================================================
 extern "C" {
 
-int mg_abi_version(void) { return 1; }
+int mg_abi_version(void) { return 2; }
 
 const char* mg_last_error(void) { return g_err.c_str(); }
 
@@ -431,6 +448,12 @@ int mg_destroy(mg_handle h) {
     for (auto& kv : h->taps) kv.second.release();
     for (auto e : h->event_pool) hipEventDestroy(e);
     delete h;
+    return 0;
+}
+
+int mg_set_precision(mg_handle h, int mode) {
+    if (!h || (mode != MG_PREC_F32 && mode != MG_PREC_F16X3)) return fail(MG_ERR_ARG, "bad precision mode");
+    h->precision = mode;
     return 0;
 }
 
@@ -551,13 +574,15 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
     float* heat = h->buf("sp.heat", n8 * 64);
     if (!a1 || !p1 || !a2 || !p2 || !a3 || !p3 || !a4 || !f4 || !cP || !cD || !lg || !dd || !heat) return fail(MG_ERR_HIP, "workspace allocation failed");
 
+    const bool f16 = h->precision == MG_PREC_F16X3;
     {
         ProfScope ps(h, s, "sp.conv1a");
         Conv1aArgs a;
         a.image = image; a.B = B; a.C = C; a.H = H; a.W = W;
         a.w = h->c1a_w; a.bias = h->c1a_b; a.post_scale = h->c1a_ps; a.post_shift = h->c1a_pt; a.out = a1;
-        launch_conv1a(a, s);
+        if (f16) launch_conv1a_sh8(a, s); else launch_conv1a(a, s);
     }
+    if (int rc = tap_copy(h, "sp.conv1a", a1, n1 * 64, s)) return rc;
     struct Step { const char* name; int layer; const float* in; float* out; int Hh, Ww, pool; };
     const Step steps[9] = {
         {"sp.conv1b", 0, a1, p1, H, W, 1},   {"sp.conv2a", 1, p1, a2, H2, W2, 0}, {"sp.conv2b", 2, a2, p2, H2, W2, 1},
@@ -566,10 +591,23 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
     for (const Step& st : steps) {
         ProfScope ps(h, s, st.name);
         const ConvLayer& L = h->conv[st.layer];
-        ConvArgs a;
-        a.in = st.in; a.Wt = L.W; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
-        a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = st.pool; a.relu = 1;
-        launch_conv3x3(a, s);
+        if (f16) {
+            ConvF16Args a;
+            a.in = st.in; a.Wt = L.Wh; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
+            a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = st.pool; a.relu = 1;
+            a.out_f32 = st.layer >= 7;  // convPa / convDa feed the fp32 1x1 heads
+            launch_conv3x3_f16x3(a, s);
+        } else {
+            ConvArgs a;
+            a.in = st.in; a.Wt = L.W; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
+            a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = st.pool; a.relu = 1;
+            launch_conv3x3(a, s);
+        }
+        if (!h->taps.empty()) {
+            const int Ho = st.pool ? st.Hh / 2 : st.Hh, Wo = st.pool ? st.Ww / 2 : st.Ww;
+            if (int rc = tap_copy(h, std::string(st.name), st.out, (size_t)B * Ho * Wo * L.Cout, s)) return rc;
+        }
+        continue;
     }
     {
         ProfScope ps(h, s, "sp.convPb");

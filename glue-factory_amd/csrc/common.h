@@ -47,3 +47,44 @@ __device__ __host__ __forceinline__ float key_to_float(uint32_t k) {
     uint32_t u = (k & 0x80000000u) ? (k & 0x7fffffffu) : ~k;
     return __builtin_bit_cast(float, u);
 }
+
+// ---- split-fp16 ("f16x3") arithmetic ------------------------------------------------------------
+// x = hi + lo with hi = fp16(x), lo = fp16(x - hi): 22 significant bits.  A product is evaluated as
+// hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_f16 with fp32 accumulation (the lo*lo term, 2^-22
+// relative, is dropped): fp32-class accuracy at 1/3 of the dense f16 MFMA rate = 5.3x the fp32 MFMA rate.
+//
+// SH8 storage of a (rows, C) fp32-equivalent tensor: per row, channels in groups of 8, each group
+// = 16 B of hi halves followed by 16 B of lo halves -> the same 4 B/element as fp32, and every MFMA
+// fragment (8 consecutive k for one row) is one aligned 16-byte piece.
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ f32x16 mfma16(f16x8 a, f16x8 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0);
+}
+// c += a*b with a = ah+al, b = bh+bl
+__device__ __forceinline__ void mma3(const f16x8 ah, const f16x8 al, const f16x8 bh, const f16x8 bl, f32x16& c) {
+    c = mfma16(ah, bh, c);
+    c = mfma16(ah, bl, c);
+    c = mfma16(al, bh, c);
+}
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ void split8(const f32x8 v, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const _Float16 h = (_Float16)v[j];
+        hi[j] = h;
+        lo[j] = (_Float16)(v[j] - (float)h);
+    }
+}
+__device__ __forceinline__ float dpp_quad_xor1(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0xB1, 0xF, 0xF, false));
+}
+__device__ __forceinline__ float dpp_quad_xor2(float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
+}
+// Exchange: lanes 32-63 of a <-> lanes 0-31 of b (v_permlane32_swap).  Inline asm on purpose: with
+// ROCm 7.2's hipcc the second result of __builtin_amdgcn_permlane32_swap is lowered to the first one
+// (tests/micro/swap_test.hip shows it).  The two v_nop cover the VALU-write -> permlane-read hazard.
+__device__ __forceinline__ void half_swap(float& a, float& b) {
+    asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}

@@ -1,0 +1,274 @@
+// SuperPoint 3x3 convolutions on the f16 MFMA with split-fp16 operands (common.h: "f16x3").
+//
+// Same implicit-GEMM structure as conv.hip, re-cut for the 16x faster matrix pipe:
+//   * activations and weights are stored SH8 (hi/lo half groups), so every fragment is one 16-byte
+//     LDS read and no conversion happens in the main loop;
+//   * Cin advances in chunks of 16 (one 32x32x16 MFMA k-step); the halo tile is [pixel][64 B] with the
+//     pixel pitch chosen == 8 (mod 16) and the four 16-byte pieces of a pixel XOR-swizzled by
+//     (pixel>>2)&3 -- every ds_read_b128 of the pixel operand and of the [tap][cout][64 B] weight
+//     slice is bank-conflict-free without padding;
+//   * weights are the A operand (rows = output channels) and pixels the B operand (lanes), so after
+//     bias/ReLU/affine a 2x2 max-pool is two quad DPP max-ops, one v_permlane32_swap per register pair
+//     leaves 16 consecutive channels of one pixel in a lane, and the lane stores 64 contiguous bytes
+//     (SH8 for the next MFMA consumer, or plain fp32 NHWC).
+// A workgroup is 8 waves (16x32 or 32x16 pixels x 64 channels), one per CU with two waves per SIMD:
+// one 83 KB LDS stage, the next chunk prefetched into registers while the current one is multiplied.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int CT = 512;  // threads per workgroup
+
+template <int WY, int WX>
+__global__ __launch_bounds__(CT, 2) void conv3x3_f16x3_kernel(const ConvF16Args p) {
+    constexpr int TH = 4 * WY, TW = 16 * WX;
+    constexpr int PW = ((TW + 2 + 7) / 16) * 16 + 8;  // pixel pitch == 8 (mod 16), >= TW + 2
+    constexpr int NPIX = (TH + 2) * (TW + 2);
+    constexpr int NIN = (NPIX * 4 + CT - 1) / CT;
+    constexpr int NWT = (9 * 64 * 4 + CT - 1) / CT;
+    __shared__ uint4 s_in[(TH + 2) * PW * 4];
+    __shared__ uint4 s_w[9 * 64 * 4];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int y0 = (blockIdx.x / tiles_x) * TH, x0 = (blockIdx.x % tiles_x) * TW;
+    const int n0 = blockIdx.y * 64;
+    const int b = blockIdx.z;
+    const int cin4 = p.Cin >> 2;  // uint4 per pixel
+    const uint4* in = reinterpret_cast<const uint4*>(p.in) + (long long)b * p.H * p.W * cin4;
+    const uint4* wt = reinterpret_cast<const uint4*>(p.Wt);
+
+    int in_goff[NIN], in_loff[NIN];
+#pragma unroll
+    for (int i = 0; i < NIN; ++i) {
+        const int idx = t + CT * i;
+        const int pix = idx >> 2, q = idx & 3;
+        const int py = pix / (TW + 2), px = pix - py * (TW + 2);
+        const int gy = y0 + py - 1, gx = x0 + px - 1;
+        const bool in_tile = idx < NPIX * 4;
+        const bool ok = in_tile && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const int P = py * PW + px;
+        in_goff[i] = ok ? ((gy * p.W + gx) * cin4 + q) : -1;
+        in_loff[i] = in_tile ? (P * 4 + (q ^ ((P >> 2) & 3))) : -1;
+    }
+
+    uint4 rin[NIN], rwt[NWT];
+    const int nchunks = p.Cin >> 4;
+    auto load_chunk = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) rin[i] = (in_goff[i] >= 0) ? in[in_goff[i] + c * 4] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int idx = t + CT * i, row = idx >> 2, q = idx & 3, tap = row >> 6, n = row & 63;
+            rwt[i] = (idx < 9 * 64 * 4) ? wt[((long long)(c * 9 + tap) * p.CoutPad + n0 + n) * 4 + q] : uint4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_chunk = [&]() {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i)
+            if (in_loff[i] >= 0) s_in[in_loff[i]] = rin[i];
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int idx = t + CT * i, row = idx >> 2, q = idx & 3;
+            if (idx < 9 * 64 * 4) s_w[row * 4 + (q ^ ((row >> 2) & 3))] = rwt[i];
+        }
+    };
+
+    f32x16 acc[2][2];  // [cout tile][pixel tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wy0 = (wave / WX) * 4, wx0 = (wave % WX) * 16;
+    const int i32 = lane & 31, h = lane >> 5;
+    // pixel operand: lane n -> pixel (dy,dx) = ((n>>1)&1, n&1) of 2x2 block n>>2 (blocks along x)
+    const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
+    // weight operand: row = tap*64 + mt*32 + i32; swizzle term depends on i32 only
+    const int wsw = (i32 >> 2) & 3;
+    const int a_hi = i32 * 4 + ((2 * h) ^ wsw), a_lo = i32 * 4 + ((2 * h + 1) ^ wsw);
+
+    load_chunk(0);
+    for (int c = 0; c < nchunks; ++c) {
+        __syncthreads();  // everyone is done reading the previous chunk
+        store_chunk();
+        __syncthreads();
+        if (c + 1 < nchunks) load_chunk(c + 1);
+        const f16x8* si = reinterpret_cast<const f16x8*>(s_in);
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                f16x8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int P = P0 + (2 * nt + ky) * PW + kx;
+                    const int sw4 = (P >> 2) & 3;
+                    bh[nt] = si[P * 4 + ((2 * h) ^ sw4)];
+                    bl[nt] = si[P * 4 + ((2 * h + 1) ^ sw4)];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int ro = ((ky * 3 + kx) * 64 + mt * 32) * 4;
+                    ah[mt] = sw[ro + a_hi];
+                    al[mt] = sw[ro + a_lo];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) mma3(ah[mt], al[mt], bh[nt], bl[nt], acc[mt][nt]);
+            }
+        }
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    const int Ho = p.pool ? p.H / 2 : p.H, Wo = p.pool ? p.W / 2 : p.W;
+    const int dy = (i32 >> 1) & 1, dx = i32 & 1, blk = i32 >> 2;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        // register r of this lane is output channel cb + 8*(r>>2) + 4*h + (r&3)
+        const int cb = n0 + mt * 32;
+        float bias[16], ps[16], pt[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = cb + 8 * (r >> 2) + 4 * h + (r & 3);
+            const bool ok = ch < p.Cout;
+            bias[r] = ok ? p.bias[ch] : 0.f;
+            ps[r] = (p.post_scale && ok) ? p.post_scale[ch] : 1.f;
+            pt[r] = (p.post_shift && ok) ? p.post_shift[ch] : 0.f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[mt][nt][r] + bias[r];
+                if (p.relu) x = fmaxf(x, 0.f);
+                if (p.post_scale) x = __fadd_rn(__fmul_rn(x, ps[r]), pt[r]);
+                if (p.pool) {
+                    x = fmaxf(x, dpp_quad_xor1(x));
+                    x = fmaxf(x, dpp_quad_xor2(x));
+                }
+                v[r] = x;
+            }
+            // gather 16 consecutive channels per lane: lanes 0-31 get cb+0..15, lanes 32-63 get cb+16..31
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                half_swap(v[e], v[8 + e]);
+                half_swap(v[4 + e], v[12 + e]);
+            }
+            // now (lower | upper half): v[0..3],v[8..11] = channels +0..7 | +16..23 ; v[4..7],v[12..15] = +8..15 | +24..31
+            const f32x8 g0 = {v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]};
+            const f32x8 g1 = {v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]};
+            int oy, ox;
+            bool ok;
+            if (p.pool) {
+                oy = (y0 + wy0 + 2 * nt) >> 1;
+                ox = ((x0 + wx0) >> 1) + blk;
+                ok = ((i32 & 3) == 0) && oy < Ho && ox < Wo;
+            } else {
+                oy = y0 + wy0 + 2 * nt + dy;
+                ox = x0 + wx0 + 2 * blk + dx;
+                ok = oy < Ho && ox < Wo;
+            }
+            const int ch0 = cb + 16 * h;
+            if (ok && ch0 < p.Cout) {
+                const long long pix = ((long long)b * Ho + oy) * Wo + ox;
+                if (p.out_f32) {
+                    float* o = reinterpret_cast<float*>(p.out) + pix * p.Cout + ch0;
+                    *reinterpret_cast<f32x4*>(o) = f32x4{g0[0], g0[1], g0[2], g0[3]};
+                    *reinterpret_cast<f32x4*>(o + 4) = f32x4{g0[4], g0[5], g0[6], g0[7]};
+                    *reinterpret_cast<f32x4*>(o + 8) = f32x4{g1[0], g1[1], g1[2], g1[3]};
+                    *reinterpret_cast<f32x4*>(o + 12) = f32x4{g1[4], g1[5], g1[6], g1[7]};
+                } else {
+                    f16x8 hi0, lo0, hi1, lo1;
+                    split8(g0, hi0, lo0);
+                    split8(g1, hi1, lo1);
+                    f16x8* o = reinterpret_cast<f16x8*>(p.out) + (pix * p.Cout + ch0) / 4;
+                    o[0] = hi0; o[1] = lo0; o[2] = hi1; o[3] = lo1;
+                }
+            }
+        }
+    }
+}
+
+// conv1a writing SH8: 8 lanes per pixel, 8 output channels each (one hi + one lo 16-byte piece).
+__global__ __launch_bounds__(256) void conv1a_sh8_kernel(const Conv1aArgs p) {
+    __shared__ float s_w[64 * 9 + 64 * 3];
+    for (int i = threadIdx.x; i < 64 * 9; i += 256) s_w[i] = p.w[i];
+    for (int i = threadIdx.x; i < 64; i += 256) {
+        s_w[576 + i] = p.bias[i];
+        s_w[640 + i] = p.post_scale ? p.post_scale[i] : 1.f;
+        s_w[704 + i] = p.post_shift ? p.post_shift[i] : 0.f;
+    }
+    __syncthreads();
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long pix = gid >> 3;
+    const int cg = (int)(gid & 7);
+    const long long HW = (long long)p.H * p.W;
+    if (pix >= (long long)p.B * HW) return;
+    const int b = (int)(pix / HW);
+    const int rem = (int)(pix - (long long)b * HW);
+    const int y = rem / p.W, x = rem - y * p.W;
+    const float* img = p.image + (long long)b * p.C * HW;
+    float g[9];
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int yy = y + ky - 1, xx = x + kx - 1;
+            float v = 0.f;
+            if (yy >= 0 && yy < p.H && xx >= 0 && xx < p.W) {
+                const long long o = (long long)yy * p.W + xx;
+                if (p.C == 3)
+                    v = __fadd_rn(__fadd_rn(__fmul_rn(img[o], 0.299f), __fmul_rn(img[HW + o], 0.587f)), __fmul_rn(img[2 * HW + o], 0.114f));
+                else
+                    v = img[o];
+            }
+            g[ky * 3 + kx] = v;
+        }
+    f32x8 o8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const int c = cg * 8 + j;
+        float a = 0.f;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a = fmaf(s_w[c * 9 + k], g[k], a);
+        a += s_w[576 + c];
+        a = fmaxf(a, 0.f);
+        if (p.post_scale) a = __fadd_rn(__fmul_rn(a, s_w[640 + c]), s_w[704 + c]);
+        o8[j] = a;
+    }
+    f16x8 hi, lo;
+    split8(o8, hi, lo);
+    f16x8* o = reinterpret_cast<f16x8*>(p.out) + pix * 16 + cg * 2;
+    o[0] = hi;
+    o[1] = lo;
+}
+
+}  // namespace
+
+void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
+    auto waste = [&](int th, int tw) {
+        long long ty = (a.H + th - 1) / th, tx = (a.W + tw - 1) / tw;
+        return ty * th * tx * tw;
+    };
+    const long long w42 = waste(16, 32), w81 = waste(32, 16);
+    const int nslices = (a.Cout + 63) / 64;
+    if (w42 <= w81) {
+        dim3 grid(((a.H + 15) / 16) * ((a.W + 31) / 32), nslices, a.B);
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<4, 2>), grid, dim3(CT), 0, s, a);
+    } else {
+        dim3 grid(((a.H + 31) / 32) * ((a.W + 15) / 16), nslices, a.B);
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<8, 1>), grid, dim3(CT), 0, s, a);
+    }
+}
+
+void launch_conv1a_sh8(const Conv1aArgs& a, hipStream_t s) {
+    const long long threads = (long long)a.B * a.H * a.W * 8;
+    hipLaunchKernelGGL(conv1a_sh8_kernel, dim3((unsigned)((threads + 255) / 256)), dim3(256), 0, s, a);
+}

@@ -61,6 +61,23 @@ struct Conv1aArgs {
 };
 void launch_conv1a(const Conv1aArgs& a, hipStream_t s);
 
+// ---- conv_f16.hip : same convolutions on the f16 MFMA with split-fp16 (SH8) operands -------------
+struct ConvF16Args {
+    const void* in = nullptr;    // SH8 NHWC (B,H,W,Cin)
+    const void* Wt = nullptr;    // SH8 tiled [Cin/16][9][CoutPad][64 B]
+    int CoutPad = 0;
+    const float* bias = nullptr;
+    const float* post_scale = nullptr;
+    const float* post_shift = nullptr;
+    void* out = nullptr;         // SH8 NHWC (or fp32 NHWC when out_f32)
+    int B = 0, H = 0, W = 0, Cin = 0, Cout = 0;
+    int pool = 0;
+    int relu = 1;
+    int out_f32 = 0;
+};
+void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s);
+void launch_conv1a_sh8(const Conv1aArgs& a, hipStream_t s);
+
 // ---- sp_post.hip ---------------------------------------------------------------------------------
 void launch_softmax_d2s(const float* logits, int ld, int B, int hc, int wc, float* heat, hipStream_t s);
 void launch_l2norm_rows(float* x, long long rows, int dim, hipStream_t s);

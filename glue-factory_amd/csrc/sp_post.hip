@@ -74,36 +74,53 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // tile per block with a 5r halo (the dependency radius of the three keep/suppress rounds).
 // max_pool2d pads with -inf, so everything outside the image is -inf / "not kept".
 constexpr int NMS_TILE = 32;
-constexpr int NMS_TMAX = NMS_TILE + 10 * 4;  // radius <= 4
+constexpr int COUNT_STRIDE = 32;  // ints between per-image candidate counters (one 128-B line each)
 
-__device__ __forceinline__ void pool_pass(const float* src, float* tmp, float* dst, int T, int r) {
-    const int n = T * T;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int y = i / T, x = i - y * T;
-        const int lo = max(x - r, 0), hi = min(x + r, T - 1);
-        float m = src[y * T + lo];
-        for (int k = lo + 1; k <= hi; ++k) m = fmaxf(m, src[y * T + k]);
-        tmp[i] = m;
+// Separable (2R+1)^2 max-pool over a TxT LDS tile (row stride TP).  Each thread produces 4 adjacent
+// outputs from a 4+2R register window, so a pass costs (4+2R)/4 LDS reads per element instead of
+// 2R+1.  Indices are clamped into the tile: a duplicated edge value cannot change a maximum.
+template <int R, int T, int TP>
+__device__ __forceinline__ void pool_pass(const float* src, float* tmp, float* dst) {
+    constexpr int G = (T + 3) / 4;  // groups of 4 along the pooled axis
+    for (int i = threadIdx.x; i < T * G; i += 256) {
+        const int y = i / G, x0 = (i - y * G) * 4;
+        float w[4 + 2 * R];
+#pragma unroll
+        for (int k = 0; k < 4 + 2 * R; ++k) w[k] = src[y * TP + min(max(x0 + k - R, 0), T - 1)];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float m = w[j];
+#pragma unroll
+            for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, w[j + k]);
+            if (x0 + j < T) tmp[y * TP + x0 + j] = m;
+        }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const int y = i / T, x = i - y * T;
-        const int lo = max(y - r, 0), hi = min(y + r, T - 1);
-        float m = tmp[lo * T + x];
-        for (int k = lo + 1; k <= hi; ++k) m = fmaxf(m, tmp[k * T + x]);
-        dst[i] = m;
+    for (int i = threadIdx.x; i < T * G; i += 256) {
+        const int g = i / T, x = i - g * T, y0 = g * 4;
+        float w[4 + 2 * R];
+#pragma unroll
+        for (int k = 0; k < 4 + 2 * R; ++k) w[k] = tmp[min(max(y0 + k - R, 0), T - 1) * TP + x];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float m = w[j];
+#pragma unroll
+            for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, w[j + k]);
+            if (y0 + j < T) dst[(y0 + j) * TP + x] = m;
+        }
     }
     __syncthreads();
 }
 
+template <int R>
 __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
-    __shared__ float s_s[NMS_TMAX * NMS_TMAX];
-    __shared__ float s_a[NMS_TMAX * NMS_TMAX];
-    __shared__ float s_t[NMS_TMAX * NMS_TMAX];
-    __shared__ unsigned char s_keep[NMS_TMAX * NMS_TMAX];
-    __shared__ unsigned char s_supp[NMS_TMAX * NMS_TMAX];
+    constexpr int halo = 5 * R, T = NMS_TILE + 2 * halo, TP = (T + 3) / 4 * 4 + 1, n = T * T;
+    __shared__ float s_s[T * TP];
+    __shared__ float s_a[T * TP];
+    __shared__ float s_t[(T * TP > 2048) ? T * TP : 2048];  // also the 1024-entry u64 candidate staging
+    __shared__ unsigned char s_keep[T * TP];
+    __shared__ unsigned char s_supp[T * TP];
 
-    const int r = p.radius, halo = 5 * r, T = NMS_TILE + 2 * halo, n = T * T;
     const int b = blockIdx.z;
     const int y0 = blockIdx.y * NMS_TILE - halo, x0 = blockIdx.x * NMS_TILE - halo;
     const float* heat = p.heat + (long long)b * p.Hs * p.Ws;
@@ -112,37 +129,50 @@ __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
     for (int i = threadIdx.x; i < n; i += 256) {
         const int y = i / T, x = i - y * T;
         const int gy = y0 + y, gx = x0 + x;
-        s_s[i] = (gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws) ? heat[(long long)gy * p.Ws + gx] : NEG;
+        s_s[y * TP + x] = (gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws) ? heat[(long long)gy * p.Ws + gx] : NEG;
     }
     __syncthreads();
-    if (r > 0) {
-        pool_pass(s_s, s_t, s_a, T, r);
-        for (int i = threadIdx.x; i < n; i += 256) s_keep[i] = (s_s[i] != NEG) && (s_s[i] == s_a[i]);
+    if (R > 0) {
+        pool_pass<R, T, TP>(s_s, s_t, s_a);
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const int y = i / T, o = y * TP + (i - y * T);
+            s_keep[o] = (s_s[o] != NEG) && (s_s[o] == s_a[o]);
+        }
         __syncthreads();
         for (int it = 0; it < 2; ++it) {
-            for (int i = threadIdx.x; i < n; i += 256) s_a[i] = s_keep[i] ? 1.f : 0.f;
-            __syncthreads();
-            pool_pass(s_a, s_t, s_a, T, r);
             for (int i = threadIdx.x; i < n; i += 256) {
-                const unsigned char sp = s_a[i] > 0.f;
-                s_supp[i] = sp;
-                s_a[i] = (s_s[i] == NEG) ? NEG : (sp ? 0.f : s_s[i]);
+                const int y = i / T, o = y * TP + (i - y * T);
+                s_a[o] = s_keep[o] ? 1.f : 0.f;
             }
             __syncthreads();
-            pool_pass(s_a, s_t, s_a, T, r);
+            pool_pass<R, T, TP>(s_a, s_t, s_a);
             for (int i = threadIdx.x; i < n; i += 256) {
-                if (s_s[i] == NEG) continue;
-                const float rest = s_supp[i] ? 0.f : s_s[i];
-                if ((rest == s_a[i]) && !s_supp[i]) s_keep[i] = 1;
+                const int y = i / T, o = y * TP + (i - y * T);
+                const unsigned char sp = s_a[o] > 0.f;
+                s_supp[o] = sp;
+                s_a[o] = (s_s[o] == NEG) ? NEG : (sp ? 0.f : s_s[o]);
+            }
+            __syncthreads();
+            pool_pass<R, T, TP>(s_a, s_t, s_a);
+            for (int i = threadIdx.x; i < n; i += 256) {
+                const int y = i / T, o = y * TP + (i - y * T);
+                if (s_s[o] == NEG) continue;
+                const float rest = s_supp[o] ? 0.f : s_s[o];
+                if ((rest == s_a[o]) && !s_supp[o]) s_keep[o] = 1;
             }
             __syncthreads();
         }
     } else {
-        for (int i = threadIdx.x; i < n; i += 256) s_keep[i] = 1;  // radius 0: every pixel is its own maximum
+        for (int i = threadIdx.x; i < T * TP; i += 256) s_keep[i] = 1;  // radius 0: every pixel is its own maximum
         __syncthreads();
     }
 
-    // interior 32x32: border mask, optional dump, candidate append
+    // interior 32x32: border mask, optional dump, candidate compaction.  Candidates are first packed
+    // in LDS so the block makes ONE global atomic (per-image counters sit on separate 128-B lines).
+    __shared__ int s_cnt, s_base;
+    unsigned long long* s_cand = reinterpret_cast<unsigned long long*>(s_t);  // >= 1024 entries
+    if (threadIdx.x == 0) s_cnt = 0;
+    __syncthreads();
     int hlim = p.Hs, wlim = p.Ws;
     if (p.image_size) {
         wlim = (int)p.image_size[2 * b];
@@ -152,7 +182,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
         const int ty = i >> 5, tx = i & 31;
         const int gy = blockIdx.y * NMS_TILE + ty, gx = blockIdx.x * NMS_TILE + tx;
         if (gy >= p.Hs || gx >= p.Ws) continue;
-        const int li = (ty + halo) * T + tx + halo;
+        const int li = (ty + halo) * TP + tx + halo;
         float v = s_keep[li] ? s_s[li] : 0.f;
         if (p.border > 0) {
             if (gy < p.border || gx < p.border || gy >= hlim - p.border || gx >= wlim - p.border) v = -1.f;
@@ -160,10 +190,17 @@ __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
         const unsigned idx = (unsigned)(gy * p.Ws + gx);
         if (p.nms_out) p.nms_out[(long long)b * p.Hs * p.Ws + idx] = v;
         if (v > p.threshold) {
-            const int pos = atomicAdd(&p.counts[b], 1);
-            p.cand[(long long)b * p.Hs * p.Ws + pos] = ((unsigned long long)float_to_key(v) << 32) | (0xFFFFFFFFu - idx);
+            const int pos = atomicAdd(&s_cnt, 1);
+            s_cand[pos] = ((unsigned long long)float_to_key(v) << 32) | (0xFFFFFFFFu - idx);
         }
     }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt == 0) return;
+    if (threadIdx.x == 0) s_base = atomicAdd(&p.counts[b * COUNT_STRIDE], cnt);
+    __syncthreads();
+    unsigned long long* dst = p.cand + (long long)b * p.Hs * p.Ws + s_base;
+    for (int i = threadIdx.x; i < cnt; i += 256) dst[i] = s_cand[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -181,7 +218,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const DetectArgs p)
     __shared__ int s_want, s_cnt;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int n = p.counts[b];
+    const int n = p.counts[b * COUNT_STRIDE];
     const int K = p.K;
     const unsigned long long* cand = p.cand + (long long)b * p.Hs * p.Ws;
     int P = 1;
@@ -351,9 +388,15 @@ void launch_nchw_to_nhwc(const float* in, float* out, int B, int HW, int C, hipS
 }
 
 void launch_detect(const DetectArgs& a, hipStream_t s) {
-    hipMemsetAsync(a.counts, 0, sizeof(int) * a.B, s);
+    (void)hipMemsetAsync(a.counts, 0, sizeof(int) * a.B * COUNT_STRIDE, s);
     dim3 grid((a.Ws + NMS_TILE - 1) / NMS_TILE, (a.Hs + NMS_TILE - 1) / NMS_TILE, a.B);
-    hipLaunchKernelGGL(nms_kernel, grid, dim3(256), 0, s, a);
+    switch (a.radius) {
+        case 0: hipLaunchKernelGGL(nms_kernel<0>, grid, dim3(256), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(nms_kernel<1>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(nms_kernel<2>, grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(nms_kernel<3>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(nms_kernel<4>, grid, dim3(256), 0, s, a); break;
+    }
     hipLaunchKernelGGL(select_kernel, dim3(a.B), dim3(SEL_THREADS), 0, s, a);
 }
 

@@ -18,7 +18,7 @@ MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN = 0, 1, 2
 
 # every symbol include/matchglue.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_weight", "mg_weights_ready",
+    "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_precision", "mg_set_weight", "mg_weights_ready",
     "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_debug_request", "mg_debug_read",
     "mg_profile_enable", "mg_profile_read", "mg_test_linear",
 ]
@@ -56,6 +56,7 @@ def lib():
     L.mg_last_error.restype = c_char_p
     L.mg_create.argtypes = [c_int, POINTER(c_void_p)]
     L.mg_destroy.argtypes = [c_void_p]
+    L.mg_set_precision.argtypes = [c_void_p, c_int]
     L.mg_set_weight.argtypes = [c_void_p, c_int, c_char_p, c_void_p, POINTER(c_int64), c_int]
     L.mg_weights_ready.argtypes = [c_void_p, c_int, c_int]
     L.mg_sp_forward.argtypes = [c_void_p, POINTER(SpConf), c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
@@ -115,6 +116,13 @@ class Engine:
             self.close()
         except Exception:
             pass
+
+    def set_precision(self, mode):
+        """'f32' (fp32-input MFMA) or 'f16x3' (split-fp16 operands on the f16 MFMA)."""
+        code = {"f32": 0, "f16x3": 1}.get(mode)
+        if code is None:
+            raise ValueError(f"precision must be 'f32' or 'f16x3', got {mode!r}")
+        _check(lib().mg_set_precision(self._h, code))
 
     # -- weights ---------------------------------------------------------------------------------
     def set_weights(self, which, state_dict, variant_or_layers):

@@ -197,6 +197,7 @@ class NativeModel(BaseModel):
             if self._engine is not None:
                 self._engine.close()
             self._engine = _native.Engine(torch.device("cuda", idx))
+            self._engine.set_precision(self.conf.get("precision", "f16x3"))
             self._uploaded_version = -1
         if self._uploaded_version != self._weights_version:
             if not self.are_weights_initialized:

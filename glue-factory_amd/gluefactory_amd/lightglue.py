@@ -34,6 +34,7 @@ class LightGlue(NativeModel):
         "weights_from_version": "v0.1_arxiv",
         "loss": {"gamma": 1.0, "fn": "nll", "nll_balancing": 0.5},
         "return_log_assignment": True,  # build-specific: skip the (B,M+1,N+1) export when False
+        "precision": "f16x3",  # build-specific: "f32" = fp32-input MFMA, "f16x3" = split-fp16 on the f16 MFMA
     }
     required_data_keys = ["keypoints0", "keypoints1", "descriptors0", "descriptors1"]
     which = 1

@@ -36,6 +36,7 @@ class SuperPoint(NativeModel):
         "remove_borders": 4,
         "legacy_sampling": True,
         "weights": None,  # local path of a state_dict (this build never downloads)
+        "precision": "f16x3",  # build-specific: "f32" = fp32-input MFMA, "f16x3" = split-fp16 on the f16 MFMA
     }
     required_data_keys = ["image"]
     which = 0

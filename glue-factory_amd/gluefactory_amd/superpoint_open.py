@@ -21,6 +21,7 @@ class SuperPoint(_SuperPointBase):
         "channels": [64, 64, 128, 128, 256],
         "dense_outputs": None,
         "weights": None,
+        "precision": "f16x3",
     }
     variant = _native.MG_SP_OPEN
     _prefixes = ("backbone", "detector", "descriptor")

@@ -66,6 +66,13 @@ const char* mg_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
 int mg_abi_version(void);
 
+/* -- arithmetic ------------------------------------------------------------------------------
+ * MG_PREC_F32   : fp32-input MFMA everywhere (v_mfma_f32_32x32x2_f32), bit-for-bit an fp32 FMA chain.
+ * MG_PREC_F16X3 : matrix work on the f16 MFMA with split-fp16 operands (x = hi + lo, three products,
+ *                 fp32 accumulation): ~2^-21 relative operand error, 5.3x the fp32 MFMA rate.        */
+enum mg_precision { MG_PREC_F32 = 0, MG_PREC_F16X3 = 1 };
+int mg_set_precision(mg_handle h, int mode);
+
 /* -- weights ---------------------------------------------------------------------------------
  * Upload one tensor of a reference state_dict, addressed by its reference key name
  * ("conv1a.weight", "backbone.0.0.bn.running_var", "transformers.3.self_attn.Wqkv.weight", ...).

@@ -149,7 +149,8 @@ def _sp_module(variant, dev, **conf):
     return m
 
 
-def test_superpoint_golden(dev, golden):
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
+def test_superpoint_golden(dev, golden, precision):
     g = golden("superpoint")
     n = 0
     for key in g.keys():
@@ -161,7 +162,7 @@ def test_superpoint_golden(dev, golden):
         conf = dict(nms_radius=r, detection_threshold=0.0 if r == 3 else 0.005, max_num_keypoints=k, force_num_keypoints=(crop == "b2_g48x64"))
         if variant == "ml_fixed":
             conf["legacy_sampling"] = False
-        m = _sp_module("open" if variant == "open" else "ml", dev, **conf)
+        m = _sp_module("open" if variant == "open" else "ml", dev, precision=precision, **conf)
         data = {"image": g[crop + ".image"].to(dev)}
         if crop == "padded":
             data["image_size"] = torch.tensor([[80, 48]], device=dev)
@@ -178,8 +179,9 @@ def test_superpoint_golden(dev, golden):
     assert n >= 14
 
 
+@pytest.mark.parametrize("precision", ["f32", "f16x3"])
 @pytest.mark.parametrize("variant", ["ml", "open"])
-def test_superpoint_dense_vs_oracle_vga(dev, variant):
+def test_superpoint_dense_vs_oracle_vga(dev, variant, precision):
     """Config-2 image size: dense heads within tolerance; keypoint set / order flips reported and bounded."""
     g = torch.Generator().manual_seed(17)
     img = torch.nn.functional.avg_pool2d(torch.rand(2, 1, 484, 644, generator=g), 5, 1)
@@ -188,7 +190,7 @@ def test_superpoint_dense_vs_oracle_vga(dev, variant):
     conf = dict(nms_radius=3, detection_threshold=0.0, max_num_keypoints=1024, force_num_keypoints=True)
     from gluefactory_amd import get_model
 
-    m = get_model("gluefactory_amd.superpoint_open" if variant == "open" else "gluefactory_amd.superpoint")({**conf, "dense_outputs": True}).eval()
+    m = get_model("gluefactory_amd.superpoint_open" if variant == "open" else "gluefactory_amd.superpoint")({**conf, "dense_outputs": True, "precision": precision}).eval()
     m.load_state_dict(W)
     ref = O.superpoint_forward({"image": img}, W, variant="open" if variant == "open" else "magicleap", **{k: v for k, v in conf.items() if k != "force_num_keypoints"})
     eng = m.engine(dev)
@@ -199,7 +201,8 @@ def test_superpoint_dense_vs_oracle_vga(dev, variant):
         a = set(map(tuple, kp[b].cpu().tolist()))
         c = set(map(tuple, ref["keypoints_list"][b].tolist()))
         same_pos = (kp[b].cpu() == ref["keypoints_list"][b]).all(-1).float().mean().item()
-        print(f"[{variant}] image {b}: keypoint set overlap {len(a & c)}/1024, same rank {same_pos:.4f}")
+        print(f"[{variant}/{precision}] max|heat err| {(heat.cpu() - ref['heatmap']).abs().max().item():.2e} max|dense err| {(dense.cpu() - ref['dense_descriptors']).abs().max().item():.2e}")
+        print(f"[{variant}/{precision}] image {b}: keypoint set overlap {len(a & c)}/1024, same rank {same_pos:.4f}")
         assert len(a & c) >= 1014  # <= 1 % membership flips at rank K from fp32 summation order
         assert same_pos > 0.97
     # stage-wise: detector fed the oracle's heatmap must be exact
