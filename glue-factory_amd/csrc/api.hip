@@ -73,6 +73,7 @@ struct ConvLayer {
 struct LinLayer {
     int N = 0, K = 0, Npad = 0;
     float *W = nullptr, *bias = nullptr, *ps = nullptr, *pt = nullptr;
+    float* Wh = nullptr;  // SH8 copy [K/16][Npad][64 B] for the f16x3 GEMM
 };
 struct LgBlock {
     LinLayer proj;  // self: Wqkv (q|k|v rows), cross: [to_qk ; to_v]
@@ -221,6 +222,21 @@ int prep_linear_rows(mg_context* h, const std::vector<const float*>& rows, const
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) t[((size_t)(k >> 3) * L->Npad + n) * 8 + (k & 7)] = rows[n][k];
     if (int rc = upload(h, t, &L->W)) return rc;
+    if (K % 16 == 0) {
+        std::vector<float> sh((size_t)(K / 16) * L->Npad * 16, 0.f);
+        _Float16* hp = reinterpret_cast<_Float16*>(sh.data());
+        for (int n = 0; n < N; ++n)
+            for (int k = 0; k < K; ++k) {
+                const float v = rows[n][k];
+                const _Float16 hi = (_Float16)v;
+                const _Float16 lo = (_Float16)(v - (float)hi);
+                const size_t row = (size_t)(k >> 4) * L->Npad + n;
+                const int grp = (k >> 3) & 1, j = k & 7;
+                hp[row * 32 + grp * 16 + j] = hi;
+                hp[row * 32 + grp * 16 + 8 + j] = lo;
+            }
+        if (int rc = upload(h, sh, &L->Wh)) return rc;
+    }
     if (!bias.empty()) return upload(h, bias, &L->bias);
     return 0;
 }
@@ -377,6 +393,22 @@ GemmArgs lin_args(const LinLayer& L, const float* A, int lda, int M, float* C, i
     g.post_shift = L.pt;
     g.C = C;
     g.ldc = ldc;
+    g.M = M;
+    g.N = L.N;
+    g.K = L.K;
+    return g;
+}
+
+GemmF16Args lin_args_f16(const LinLayer& L, const void* A, int lda, int M) {
+    GemmF16Args g;
+    g.A0 = A;
+    g.lda0 = lda;
+    g.ksplit = L.K;
+    g.W = L.Wh;
+    g.Npad = L.Npad;
+    g.bias = L.bias;
+    g.post_scale = L.ps;
+    g.post_shift = L.pt;
     g.M = M;
     g.N = L.N;
     g.K = L.K;
@@ -595,7 +627,7 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
             ConvF16Args a;
             a.in = st.in; a.Wt = L.Wh; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
             a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = st.pool; a.relu = 1;
-            a.out_f32 = st.layer >= 7;  // convPa / convDa feed the fp32 1x1 heads
+            a.out_f32 = 0;
             launch_conv3x3_f16x3(a, s);
         } else {
             ConvArgs a;
@@ -611,8 +643,14 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
     }
     {
         ProfScope ps(h, s, "sp.convPb");
-        GemmArgs g = lin_args(h->convPb, cP, 256, (int)n8, lg, 65);
-        launch_gemm(g, s);
+        if (f16) {
+            GemmF16Args g = lin_args_f16(h->convPb, cP, 256, (int)n8);
+            g.C = lg; g.ldc = 65;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g = lin_args(h->convPb, cP, 256, (int)n8, lg, 65);
+            launch_gemm(g, s);
+        }
     }
     {
         ProfScope ps(h, s, "sp.softmax_d2s");
@@ -620,8 +658,14 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
     }
     {
         ProfScope ps(h, s, "sp.convDb");
-        GemmArgs g = lin_args(h->convDb, cD, 256, (int)n8, dd, 256);
-        launch_gemm(g, s);
+        if (f16) {
+            GemmF16Args g = lin_args_f16(h->convDb, cD, 256, (int)n8);
+            g.C = dd; g.ldc = 256;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g = lin_args(h->convDb, cD, 256, (int)n8, dd, 256);
+            launch_gemm(g, s);
+        }
     }
     {
         ProfScope ps(h, s, "sp.l2norm");
@@ -673,70 +717,100 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
     }
     if (int rc = tap_copy(h, "lg.enc", ENC, T * 64, s)) return rc;
 
-    auto ffn = [&](const LgBlock& blk, const char* tag) {
+    const bool f16 = h->precision == MG_PREC_F16X3;
+    float* XS = nullptr;
+    if (f16) {
+        XS = h->buf("lg.xs", T * 256);
+        if (!XS) return fail(MG_ERR_HIP, "workspace allocation failed");
+        launch_to_sh8(X, XS, (long long)T * 256, s);
+    }
+
+    auto ffn = [&](const LgBlock& blk) {
         {
             ProfScope ps(h, s, "lg.gemm.ffn0");
-            GemmArgs g = lin_args(blk.ffn0, X, 256, (int)T, HID, 512);
-            g.A1 = MSG; g.lda1 = 256; g.ksplit = 256;
-            launch_gemm(g, s);
+            if (f16) {
+                GemmF16Args g = lin_args_f16(blk.ffn0, XS, 256, (int)T);
+                g.A1 = MSG; g.lda1 = 256; g.ksplit = 256;
+                g.C = HID; g.ldc = 512;
+                launch_gemm_f16x3(g, s);
+            } else {
+                GemmArgs g = lin_args(blk.ffn0, X, 256, (int)T, HID, 512);
+                g.A1 = MSG; g.lda1 = 256; g.ksplit = 256;
+                launch_gemm(g, s);
+            }
         }
         {
             ProfScope ps(h, s, "lg.ln_gelu");
-            launch_ln_gelu(HID, (long long)T, 512, blk.ln_g, blk.ln_b, 1e-5f, s);
+            launch_ln_gelu(HID, (long long)T, 512, blk.ln_g, blk.ln_b, 1e-5f, f16 ? 1 : 0, s);
         }
         {
             ProfScope ps(h, s, "lg.gemm.ffn3");
-            GemmArgs g = lin_args(blk.ffn3, HID, 512, (int)T, X, 256);
-            g.residual = X; g.ldr = 256;
+            if (f16) {
+                GemmF16Args g = lin_args_f16(blk.ffn3, HID, 512, (int)T);
+                g.residual = X; g.ldr = 256;
+                g.C = X; g.ldc = 256; g.Cs = XS; g.ldcs = 256;
+                launch_gemm_f16x3(g, s);
+            } else {
+                GemmArgs g = lin_args(blk.ffn3, HID, 512, (int)T, X, 256);
+                g.residual = X; g.ldr = 256;
+                launch_gemm(g, s);
+            }
+        }
+    };
+    auto proj = [&](const LgBlock& blk, const char* name, int ncols, float scale, bool rotary) {
+        ProfScope ps(h, s, name);
+        if (f16) {
+            GemmF16Args g = lin_args_f16(blk.proj, XS, 256, (int)T);
+            g.Cs = QKV; g.ldcs = ncols;
+            if (rotary) { g.enc = ENC; g.rotary_cols = 512; }
+            g.scale = scale; g.scale_cols = 256;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g = lin_args(blk.proj, X, 256, (int)T, QKV, ncols);
+            if (rotary) { g.enc = ENC; g.rotary_cols = 512; }
+            g.scale = scale; g.scale_cols = 256;
             launch_gemm(g, s);
         }
-        (void)tag;
+    };
+    auto attend = [&](const char* name, int ld, int kcol, int vcol, int cross) {
+        ProfScope ps(h, s, name);
+        if (f16) {
+            AttnF16Args a;
+            a.q = QKV; a.k = QKV; a.v = QKV; a.ld = ld; a.q_col = 0; a.k_col = kcol; a.v_col = vcol;
+            a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+            launch_attention_f16x3(a, s);
+        } else {
+            AttnArgs a;
+            a.q = QKV; a.k = QKV; a.v = QKV; a.ld = ld; a.q_col = 0; a.k_col = kcol; a.v_col = vcol;
+            a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+            launch_attention(a, s);
+        }
+    };
+    auto outproj = [&](const LgBlock& blk) {
+        ProfScope ps(h, s, "lg.gemm.out");
+        if (f16) {
+            GemmF16Args g = lin_args_f16(blk.out, CTX, 256, (int)T);
+            g.Cs = MSG; g.ldcs = 256;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g = lin_args(blk.out, CTX, 256, (int)T, MSG, 256);
+            launch_gemm(g, s);
+        }
     };
 
     for (int i = 0; i < conf->n_layers; ++i) {
         const LgBlock& sb = h->lg_self[i];
-        {
-            ProfScope ps(h, s, "lg.gemm.qkv");
-            GemmArgs g = lin_args(sb.proj, X, 256, (int)T, QKV, 768);
-            g.enc = ENC; g.rotary_cols = 512; g.scale = 0.125f; g.scale_cols = 256;
-            launch_gemm(g, s);
-        }
-        {
-            ProfScope ps(h, s, "lg.attn.self");
-            AttnArgs a;
-            a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
-            a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = 0;
-            launch_attention(a, s);
-        }
-        {
-            ProfScope ps(h, s, "lg.gemm.out");
-            GemmArgs g = lin_args(sb.out, CTX, 256, (int)T, MSG, 256);
-            launch_gemm(g, s);
-        }
-        ffn(sb, "self");
+        proj(sb, "lg.gemm.qkv", 768, 0.125f, true);
+        attend("lg.attn.self", 768, 256, 512, 0);
+        outproj(sb);
+        ffn(sb);
         if (int rc = tap_copy(h, "lg.self" + std::to_string(i), X, T * 256, s)) return rc;
 
         const LgBlock& cb = h->lg_cross[i];
-        {
-            ProfScope ps(h, s, "lg.gemm.qkv_cross");
-            GemmArgs g = lin_args(cb.proj, X, 256, (int)T, QKV, 512);
-            g.scale = 0.35355339059327373f;  // (dim_head^-0.5)^0.5, lightglue.py:200
-            g.scale_cols = 256;
-            launch_gemm(g, s);
-        }
-        {
-            ProfScope ps(h, s, "lg.attn.cross");
-            AttnArgs a;
-            a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 512; a.q_col = 0; a.k_col = 0; a.v_col = 256;
-            a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = 1;
-            launch_attention(a, s);
-        }
-        {
-            ProfScope ps(h, s, "lg.gemm.out");
-            GemmArgs g = lin_args(cb.out, CTX, 256, (int)T, MSG, 256);
-            launch_gemm(g, s);
-        }
-        ffn(cb, "cross");
+        proj(cb, "lg.gemm.qkv_cross", 512, 0.35355339059327373f, false);  // (dim_head^-0.5)^0.5, lightglue.py:200
+        attend("lg.attn.cross", 512, 0, 256, 1);
+        outproj(cb);
+        ffn(cb);
         if (int rc = tap_copy(h, "lg.layer" + std::to_string(i), X, T * 256, s)) return rc;
     }
 
@@ -744,19 +818,36 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
     float* MD = QKV;  // reuse: (T,256) projected descriptors
     {
         ProfScope ps(h, s, "lg.gemm.final_proj");
-        GemmArgs g = lin_args(h->final_proj, X, 256, (int)T, MD, 256);
-        g.scale = 0.25f;  // / 256^(1/4)
-        g.scale_cols = 256;
-        launch_gemm(g, s);
+        if (f16) {
+            GemmF16Args g = lin_args_f16(h->final_proj, XS, 256, (int)T);
+            g.Cs = MD; g.ldcs = 256;
+            g.scale = 0.25f; g.scale_cols = 256;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g = lin_args(h->final_proj, X, 256, (int)T, MD, 256);
+            g.scale = 0.25f;  // / 256^(1/4)
+            g.scale_cols = 256;
+            launch_gemm(g, s);
+        }
     }
     {
         ProfScope ps(h, s, "lg.gemm.sim");
-        GemmArgs g;
-        g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
-        g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-        g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
-        g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
-        launch_gemm(g, s);
+        if (f16) {
+            // sim[b] (M x N): lanes = image-0 tokens ("A" rows of the launcher), MFMA rows = image-1 tokens
+            GemmF16Args g;
+            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
+            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g;
+            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
+            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
+            launch_gemm(g, s);
+        }
     }
     {
         ProfScope ps(h, s, "lg.assign");

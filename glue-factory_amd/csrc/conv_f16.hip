@@ -27,17 +27,17 @@ __global__ __launch_bounds__(CT, 2) void conv3x3_f16x3_kernel(const ConvF16Args 
     constexpr int NPIX = (TH + 2) * (TW + 2);
     constexpr int NIN = (NPIX * 4 + CT - 1) / CT;
     constexpr int NWT = (9 * 64 * 4 + CT - 1) / CT;
-    __shared__ uint4 s_in[(TH + 2) * PW * 4];
-    __shared__ uint4 s_w[9 * 64 * 4];
+    __shared__ u32x4 s_in[(TH + 2) * PW * 4];
+    __shared__ u32x4 s_w[9 * 64 * 4];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int tiles_x = (p.W + TW - 1) / TW;
     const int y0 = (blockIdx.x / tiles_x) * TH, x0 = (blockIdx.x % tiles_x) * TW;
     const int n0 = blockIdx.y * 64;
     const int b = blockIdx.z;
-    const int cin4 = p.Cin >> 2;  // uint4 per pixel
-    const uint4* in = reinterpret_cast<const uint4*>(p.in) + (long long)b * p.H * p.W * cin4;
-    const uint4* wt = reinterpret_cast<const uint4*>(p.Wt);
+    const int cin4 = p.Cin >> 2;  // u32x4 per pixel
+    const u32x4* in = reinterpret_cast<const u32x4*>(p.in) + (long long)b * p.H * p.W * cin4;
+    const u32x4* wt = reinterpret_cast<const u32x4*>(p.Wt);
 
     int in_goff[NIN], in_loff[NIN];
 #pragma unroll
@@ -53,15 +53,15 @@ __global__ __launch_bounds__(CT, 2) void conv3x3_f16x3_kernel(const ConvF16Args 
         in_loff[i] = in_tile ? (P * 4 + (q ^ ((P >> 2) & 3))) : -1;
     }
 
-    uint4 rin[NIN], rwt[NWT];
+    u32x4 rin[NIN], rwt[NWT];
     const int nchunks = p.Cin >> 4;
     auto load_chunk = [&](int c) {
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) rin[i] = (in_goff[i] >= 0) ? in[in_goff[i] + c * 4] : uint4{0u, 0u, 0u, 0u};
+        for (int i = 0; i < NIN; ++i) rin[i] = (in_goff[i] >= 0) ? in[in_goff[i] + c * 4] : u32x4{0u, 0u, 0u, 0u};
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int idx = t + CT * i, row = idx >> 2, q = idx & 3, tap = row >> 6, n = row & 63;
-            rwt[i] = (idx < 9 * 64 * 4) ? wt[((long long)(c * 9 + tap) * p.CoutPad + n0 + n) * 4 + q] : uint4{0u, 0u, 0u, 0u};
+            rwt[i] = (idx < 9 * 64 * 4) ? wt[((long long)(c * 9 + tap) * p.CoutPad + n0 + n) * 4 + q] : u32x4{0u, 0u, 0u, 0u};
         }
     };
     auto store_chunk = [&]() {

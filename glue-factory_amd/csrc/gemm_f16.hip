@@ -1,0 +1,228 @@
+// C[tokens, features] = A[tokens, K] * W[features, K]^T on the f16 MFMA with split-fp16 (SH8) operands.
+//
+// Serves the Linear layers of LightGlue and SuperPoint's 1x1 heads in MG_PREC_F16X3 mode.  Structure of
+// gemm.hip (128x128 tile, 4 waves x 64x64, K in stages of 32, double-buffered LDS, register prefetch),
+// re-cut for the 16x faster pipe:
+//   * both operands arrive SH8, so a stage row is 128 contiguous bytes = eight 16-byte pieces, staged
+//     unpadded with piece index XOR (row>>1)&7 -> every fragment ds_read_b128 is conflict-free;
+//   * the weight tile is the A operand (rows = features) and the token tile the B operand (lanes), so a
+//     lane owns one token: after one v_permlane32_swap per register pair it holds 16 consecutive features
+//     -- rotary pairs are adjacent registers (no shuffle), the residual / fp32 store is 64 contiguous
+//     bytes, and the SH8 copy for the next MFMA consumer is produced in the same epilogue.
+#include "common.h"
+#include "kernels.h"
+
+namespace {
+
+constexpr int TN = 128, TM = 128, BK = 32;
+
+__device__ __forceinline__ int swz(int row, int s) { return row * 8 + (s ^ ((row >> 1) & 7)); }
+
+template <bool W_ROWMAJOR>
+__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
+    __shared__ u32x4 s_tok[2][TM * 8];
+    __shared__ u32x4 s_w[2][TN * 8];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wf = wave >> 1, wt = wave & 1;
+    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    const long long z = blockIdx.z;
+    const u32x4* A0 = reinterpret_cast<const u32x4*>(p.A0) + z * (p.strideA >> 2);
+    const u32x4* A1 = p.A1 ? reinterpret_cast<const u32x4*>(p.A1) + z * (p.strideA >> 2) : nullptr;
+    const u32x4* Wg = reinterpret_cast<const u32x4*>(p.W) + z * (p.strideW >> 2);
+
+    f32x16 acc[2][2];  // [feature tile][token tile]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    u32x4 ra[4], rw[4];
+    const int nk = p.K / BK;
+    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+
+    auto load_stage = [&](int kt) {
+        const int k0 = kt * BK;
+        const u32x4* Asrc;
+        int lda, kk;
+        if (k0 < p.ksplit) { Asrc = A0; lda = p.lda0; kk = k0; } else { Asrc = A1; lda = p.lda1; kk = k0 - p.ksplit; }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + 256 * i, row = idx >> 3, s = idx & 7;
+            const int gm = m0 + row;
+            ra[i] = (gm < p.M) ? Asrc[(((long long)gm * lda + kk) >> 2) + s] : zero4;
+        }
+        if (W_ROWMAJOR) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = t + 256 * i, row = idx >> 3, s = idx & 7;
+                const int gn = n0 + row;
+                rw[i] = (gn < p.N) ? Wg[(((long long)gn * p.ldw + k0) >> 2) + s] : zero4;
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = t + 256 * i, kc = idx >> 9, rem = idx & 511;
+                rw[i] = Wg[((long long)((k0 >> 4) + kc) * p.Npad + n0) * 4 + rem];
+            }
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = t + 256 * i, row = idx >> 3, s = idx & 7;
+            s_tok[buf][swz(row, s)] = ra[i];
+        }
+        if (W_ROWMAJOR) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = t + 256 * i, row = idx >> 3, s = idx & 7;
+                s_w[buf][swz(row, s)] = rw[i];
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int idx = t + 256 * i, kc = idx >> 9, rem = idx & 511, n = rem >> 2, q = rem & 3;
+                s_w[buf][swz(n, kc * 4 + q)] = rw[i];
+            }
+        }
+    };
+
+    load_stage(0);
+    store_stage(0);
+    __syncthreads();
+
+    const int i32 = lane & 31, h = lane >> 5;
+    for (int kt = 0; kt < nk; ++kt) {
+        const int buf = kt & 1;
+        if (kt + 1 < nk) load_stage(kt + 1);
+        const f16x8* st = reinterpret_cast<const f16x8*>(s_tok[buf]);
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w[buf]);
+#pragma unroll
+        for (int kc = 0; kc < 2; ++kc) {
+            f16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft) {
+                const int row = wf * 64 + ft * 32 + i32;
+                ah[ft] = sw[swz(row, kc * 4 + 2 * h)];
+                al[ft] = sw[swz(row, kc * 4 + 2 * h + 1)];
+            }
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) {
+                const int row = wt * 64 + tt * 32 + i32;
+                bh[tt] = st[swz(row, kc * 4 + 2 * h)];
+                bl[tt] = st[swz(row, kc * 4 + 2 * h + 1)];
+            }
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) mma3(ah[ft], al[ft], bh[tt], bl[tt], acc[ft][tt]);
+        }
+        if (kt + 1 < nk) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+
+    // ---- epilogue ---------------------------------------------------------------------------------
+    float* C = p.C ? p.C + z * p.strideC : nullptr;
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft) {
+        const int fb = n0 + wf * 64 + ft * 32 + 16 * h;  // first of this lane's 16 consecutive features
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tok = m0 + wt * 64 + tt * 32 + i32;
+            const bool tok_ok = tok < p.M;
+            f32x16 w;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float a0 = acc[ft][tt][e], b0 = acc[ft][tt][8 + e], a1 = acc[ft][tt][4 + e], b1 = acc[ft][tt][12 + e];
+                half_swap(a0, b0);
+                half_swap(a1, b1);
+                w[e] = a0; w[4 + e] = b0; w[8 + e] = a1; w[12 + e] = b1;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int f = fb + j;
+                if (p.bias && f < p.N) w[j] += p.bias[f];
+            }
+            if (p.rotary_cols > 0 && fb < p.rotary_cols) {  // lightglue.py:36-43, pairs (2i, 2i+1)
+                const float* e = p.enc + (long long)(tok_ok ? tok : 0) * 64;
+#pragma unroll
+                for (int j = 0; j < 16; j += 2) {
+                    const int fq = ((fb + j) & 63) >> 1;
+                    const float c = e[fq], s = e[fq + 32];
+                    const float xe = w[j], xo = w[j + 1];
+                    w[j] = __fadd_rn(__fmul_rn(xe, c), __fmul_rn(-xo, s));
+                    w[j + 1] = __fadd_rn(__fmul_rn(xo, c), __fmul_rn(xe, s));
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                const int f = fb + j;
+                float x = w[j];
+                if (p.relu) x = fmaxf(x, 0.f);
+                if (p.post_scale && f < p.N) x = __fadd_rn(__fmul_rn(x, p.post_scale[f]), p.post_shift[f]);
+                if (f < p.scale_cols) x *= p.scale;
+                w[j] = x;
+            }
+            if (!tok_ok || fb >= p.N) continue;
+            if (p.residual) {
+                const float* rs = p.residual + (long long)tok * p.ldr + fb;
+#pragma unroll
+                for (int j = 0; j < 16; j += 4) {
+                    const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + j);
+                    w[j] += rv.x; w[j + 1] += rv.y; w[j + 2] += rv.z; w[j + 3] += rv.w;
+                }
+            }
+            if (C) {
+                float* o = C + (long long)tok * p.ldc + fb;
+                if (fb + 16 <= p.N && (p.ldc & 3) == 0) {
+#pragma unroll
+                    for (int j = 0; j < 16; j += 4) *reinterpret_cast<f32x4*>(o + j) = f32x4{w[j], w[j + 1], w[j + 2], w[j + 3]};
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j)
+                        if (fb + j < p.N) o[j] = w[j];
+                }
+            }
+            if (p.Cs) {
+                const f32x8 g0 = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
+                const f32x8 g1 = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]};
+                f16x8 hi0, lo0, hi1, lo1;
+                split8(g0, hi0, lo0);
+                split8(g1, hi1, lo1);
+                f16x8* o = reinterpret_cast<f16x8*>(p.Cs) + (((long long)tok * p.ldcs + fb) >> 2) + z * (p.strideCs >> 2);
+                o[0] = hi0; o[1] = lo0; o[2] = hi1; o[3] = lo1;
+            }
+        }
+    }
+}
+
+// fp32 rows -> SH8 rows (entry of the LightGlue residual stream; C % 8 == 0).  One thread per group of 8.
+__global__ __launch_bounds__(256) void to_sh8_kernel(const float* __restrict__ in, void* __restrict__ out, long long groups) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(in + g * 8), b = *reinterpret_cast<const f32x4*>(in + g * 8 + 4);
+    const f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    f16x8 hi, lo;
+    split8(v, hi, lo);
+    f16x8* o = reinterpret_cast<f16x8*>(out) + g * 2;
+    o[0] = hi;
+    o[1] = lo;
+}
+
+}  // namespace
+
+void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s) {
+    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, a.batch);
+    if (a.w_rowmajor)
+        hipLaunchKernelGGL(gemm_f16x3_kernel<true>, grid, dim3(256), 0, s, a);
+    else
+        hipLaunchKernelGGL(gemm_f16x3_kernel<false>, grid, dim3(256), 0, s, a);
+}
+
+void launch_to_sh8(const float* in, void* out, long long elems, hipStream_t s) {
+    const long long groups = elems / 8;
+    hipLaunchKernelGGL(to_sh8_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, in, out, groups);
+}

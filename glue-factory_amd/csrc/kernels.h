@@ -78,6 +78,38 @@ struct ConvF16Args {
 void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s);
 void launch_conv1a_sh8(const Conv1aArgs& a, hipStream_t s);
 
+// ---- gemm_f16.hip : the same GEMM on the f16 MFMA, SH8 operands --------------------------------
+struct GemmF16Args {
+    const void* A0 = nullptr;   // SH8 rows (tokens); lda in elements
+    int lda0 = 0;
+    const void* A1 = nullptr;
+    int lda1 = 0;
+    int ksplit = 0;
+    const void* W = nullptr;    // SH8 tiled [K/16][Npad][64 B] (w_rowmajor = 0) or SH8 rows [N][ldw]
+    int Npad = 0;
+    int w_rowmajor = 0;
+    int ldw = 0;
+    const float* bias = nullptr;
+    float* C = nullptr;         // optional fp32 output (tokens, ldc)
+    int ldc = 0;
+    void* Cs = nullptr;         // optional SH8 output (tokens, ldcs)
+    int ldcs = 0;
+    int M = 0, N = 0, K = 0;    // tokens, features, reduction
+    const float* enc = nullptr;
+    int rotary_cols = 0;
+    int relu = 0;
+    const float* post_scale = nullptr;
+    const float* post_shift = nullptr;
+    float scale = 1.f;
+    int scale_cols = 0;
+    const float* residual = nullptr;
+    int ldr = 0;
+    int batch = 1;
+    long long strideA = 0, strideW = 0, strideC = 0, strideCs = 0;  // elements
+};
+void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s);
+void launch_to_sh8(const float* in, void* out, long long elems, hipStream_t s);
+
 // ---- sp_post.hip ---------------------------------------------------------------------------------
 void launch_softmax_d2s(const float* logits, int ld, int B, int hc, int wc, float* heat, hipStream_t s);
 void launch_l2norm_rows(float* x, long long rows, int dim, hipStream_t s);
@@ -121,10 +153,25 @@ struct AttnArgs {
 };
 void launch_attention(const AttnArgs& a, hipStream_t s);
 
+// ---- attention_f16.hip : SH8 operands, f16 MFMA --------------------------------------------------
+struct AttnF16Args {
+    const void* q = nullptr;  // SH8 rows of `ld` elements; head h occupies cols [q_col + 64h, +64)
+    const void* k = nullptr;
+    const void* v = nullptr;
+    int ld = 0;
+    int q_col = 0, k_col = 0, v_col = 0;
+    void* out = nullptr;      // SH8 (tokens, ldo)
+    int ldo = 0;
+    int B = 0, M = 0, N = 0;
+    int heads = 4;
+    int cross = 0;
+};
+void launch_attention_f16x3(const AttnF16Args& a, hipStream_t s);
+
 // ---- lg_misc.hip ---------------------------------------------------------------------------------
 void launch_posenc(const float* kpts0, const float* kpts1, const float* size0, const float* size1, const float* Wr,
                    int B, int M, int N, float* enc, hipStream_t s);
-void launch_ln_gelu(float* x, long long rows, int dim, const float* gamma, const float* beta, float eps, hipStream_t s);
+void launch_ln_gelu(float* x, long long rows, int dim, const float* gamma, const float* beta, float eps, int sh8, hipStream_t s);
 void launch_matchability(const float* x, long long rows, const float* w, float bias, float* z, hipStream_t s);
 struct AssignArgs {
     const float* sim = nullptr;  // (B,M,N)

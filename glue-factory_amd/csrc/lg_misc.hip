@@ -54,18 +54,20 @@ __global__ __launch_bounds__(256) void posenc_kernel(const float* __restrict__ k
     }
 }
 
-// lightglue.py:139-140 -- LayerNorm(512, eps) then exact (erf) GELU, in place.  One wave per row.
+// lightglue.py:139-140 -- LayerNorm(512, eps) then exact (erf) GELU, in place.  One wave per row, 8
+// consecutive features per lane; with `sh8` the result is written as split-fp16 over the same bytes
+// (a lane's 32 bytes of fp32 become its own hi/lo pieces, so the in-place rewrite is race-free).
 __global__ __launch_bounds__(256) void ln_gelu_kernel(float* __restrict__ x, long long rows, int dim, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float eps) {
+                                                     const float* __restrict__ beta, float eps, int sh8) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    float* p = x + row * dim;
+    float* p = x + row * dim + lane * 8;
     f32x4 v[2];
     float sum = 0.f;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        v[i] = *reinterpret_cast<const f32x4*>(p + i * 256 + lane * 4);
+        v[i] = *reinterpret_cast<const f32x4*>(p + i * 4);
         sum += v[i].x + v[i].y + v[i].z + v[i].w;
     }
     const float mean = wave_sum(sum) / (float)dim;
@@ -79,17 +81,26 @@ __global__ __launch_bounds__(256) void ln_gelu_kernel(float* __restrict__ x, lon
         }
     const float var = wave_sum(sq) / (float)dim;
     const float rstd = 1.f / sqrtf(var + eps);
+    f32x8 o;
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
-        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + i * 256 + lane * 4);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + i * 256 + lane * 4);
-        f32x4 o;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gamma + lane * 8 + i * 4);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(beta + lane * 8 + i * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float y = (v[i][j] - mean) * rstd * g[j] + bb[j];
-            o[j] = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
+            o[i * 4 + j] = 0.5f * y * (1.f + erff(y * 0.70710678118654752440f));
         }
-        *reinterpret_cast<f32x4*>(p + i * 256 + lane * 4) = o;
+    }
+    if (sh8) {
+        f16x8 hi, lo;
+        split8(o, hi, lo);
+        f16x8* q = reinterpret_cast<f16x8*>(p);
+        q[0] = hi;
+        q[1] = lo;
+    } else {
+        *reinterpret_cast<f32x4*>(p) = f32x4{o[0], o[1], o[2], o[3]};
+        *reinterpret_cast<f32x4*>(p + 4) = f32x4{o[4], o[5], o[6], o[7]};
     }
 }
 
@@ -255,8 +266,8 @@ void launch_posenc(const float* kpts0, const float* kpts1, const float* size0, c
     hipLaunchKernelGGL(posenc_kernel, dim3(2 * B), dim3(256), 0, s, kpts0, kpts1, size0, size1, Wr, B, M, N, enc);
 }
 
-void launch_ln_gelu(float* x, long long rows, int dim, const float* gamma, const float* beta, float eps, hipStream_t s) {
-    hipLaunchKernelGGL(ln_gelu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, dim, gamma, beta, eps);
+void launch_ln_gelu(float* x, long long rows, int dim, const float* gamma, const float* beta, float eps, int sh8, hipStream_t s) {
+    hipLaunchKernelGGL(ln_gelu_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, rows, dim, gamma, beta, eps, sh8);
 }
 
 void launch_matchability(const float* x, long long rows, const float* w, float bias, float* z, hipStream_t s) {
