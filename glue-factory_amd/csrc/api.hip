@@ -217,7 +217,7 @@ int prep_linear_rows(mg_context* h, const std::vector<const float*>& rows, const
     const int N = (int)rows.size();
     L->N = N;
     L->K = K;
-    L->Npad = (N + 127) / 128 * 128;
+    L->Npad = (N + 255) / 256 * 256;
     std::vector<float> t((size_t)(K / 8) * L->Npad * 8, 0.f);
     for (int n = 0; n < N; ++n)
         for (int k = 0; k < K; ++k) t[((size_t)(k >> 3) * L->Npad + n) * 8 + (k & 7)] = rows[n][k];

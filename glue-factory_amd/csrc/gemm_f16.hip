@@ -1,10 +1,12 @@
 // C[tokens, features] = A[tokens, K] * W[features, K]^T on the f16 MFMA with split-fp16 (SH8) operands.
 //
-// Serves the Linear layers of LightGlue and SuperPoint's 1x1 heads in MG_PREC_F16X3 mode.  Structure of
-// gemm.hip (128x128 tile, 4 waves x 64x64, K in stages of 32, double-buffered LDS, register prefetch),
-// re-cut for the 16x faster pipe:
-//   * both operands arrive SH8, so a stage row is 128 contiguous bytes = eight 16-byte pieces, staged
-//     unpadded with piece index XOR (row>>1)&7 -> every fragment ds_read_b128 is conflict-free;
+// Serves the Linear layers of LightGlue and SuperPoint's 1x1 heads in MG_PREC_F16X3 mode.  Re-cut for
+// the 16x faster pipe: a 256x256 tile (8 waves x 128 features x 64 tokens, K in stages of 32,
+// double-buffered 128 KB of LDS, one workgroup per CU) -- at this MFMA rate the 128x128 tile of gemm.hip
+// is bound by L2->LDS traffic (42 B/clk/CU at full rate); 256x256 halves the bytes per MFMA:
+//   * both operands arrive SH8, so a stage row is 128 contiguous bytes = eight 16-byte pieces, moved
+//     to LDS by LDS-DMA (global_load_lds) with the piece index XOR (row>>1)&7 applied on the source
+//     side -> no ds_write traffic, and every fragment ds_read_b128 is conflict-free;
 //   * the weight tile is the A operand (rows = features) and the token tile the B operand (lanes), so a
 //     lane owns one token: after one v_permlane32_swap per register pair it holds 16 consecutive features
 //     -- rotary pairs are adjacent registers (no shuffle), the residual / fp32 store is 64 contiguous
@@ -14,98 +16,80 @@
 
 namespace {
 
-constexpr int TN = 128, TM = 128, BK = 32;
+constexpr int TN = 256, TM = 256, BK = 32, GT = 512;  // 8 waves: 2 (features) x 4 (tokens), each 128 x 64
 
 __device__ __forceinline__ int swz(int row, int s) { return row * 8 + (s ^ ((row >> 1) & 7)); }
 
 template <bool W_ROWMAJOR>
-__global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
+__global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
     __shared__ u32x4 s_tok[2][TM * 8];
     __shared__ u32x4 s_w[2][TN * 8];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wf = wave >> 1, wt = wave & 1;
+    const int wf = wave >> 2, wt = wave & 3;
     const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
     const long long z = blockIdx.z;
     const u32x4* A0 = reinterpret_cast<const u32x4*>(p.A0) + z * (p.strideA >> 2);
     const u32x4* A1 = p.A1 ? reinterpret_cast<const u32x4*>(p.A1) + z * (p.strideA >> 2) : nullptr;
     const u32x4* Wg = reinterpret_cast<const u32x4*>(p.W) + z * (p.strideW >> 2);
 
-    f32x16 acc[2][2];  // [feature tile][token tile]
+    f32x16 acc[4][2];  // [feature tile][token tile]
 #pragma unroll
-    for (int i = 0; i < 2; ++i)
+    for (int i = 0; i < 4; ++i)
 #pragma unroll
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    u32x4 ra[4], rw[4];
     const int nk = p.K / BK;
-    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
 
-    auto load_stage = [&](int kt) {
+    // Stage = 128 token rows + 128 feature rows x 128 B, moved HBM/L2 -> LDS by LDS-DMA (global_load_lds,
+    // 1 KiB per wave-instruction, no VGPR round trip and no ds_write traffic).  The DMA writes LDS
+    // linearly (base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE piece instead.
+    // Rows past the edge are clamped to the last valid row (their outputs are never stored).
+    auto issue_stage = [&](int kt, int buf) {
         const int k0 = kt * BK;
         const u32x4* Asrc;
         int lda, kk;
         if (k0 < p.ksplit) { Asrc = A0; lda = p.lda0; kk = k0; } else { Asrc = A1; lda = p.lda1; kk = k0 - p.ksplit; }
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = t + 256 * i, row = idx >> 3, s = idx & 7;
-            const int gm = m0 + row;
-            ra[i] = (gm < p.M) ? Asrc[(((long long)gm * lda + kk) >> 2) + s] : zero4;
+        for (int j = 0; j < 4; ++j) {
+            const int slot = (wu * 4 + j) * 64 + lane, row = slot >> 3, sp = slot & 7;
+            const int sidx = sp ^ ((row >> 1) & 7);
+            const int gm = min(m0 + row, p.M - 1);
+            __builtin_amdgcn_global_load_lds(Asrc + (((long long)gm * lda + kk) >> 2) + sidx, &s_tok[buf][(wu * 4 + j) * 64], 16, 0, 0);
         }
-        if (W_ROWMAJOR) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = t + 256 * i, row = idx >> 3, s = idx & 7;
-                const int gn = n0 + row;
-                rw[i] = (gn < p.N) ? Wg[(((long long)gn * p.ldw + k0) >> 2) + s] : zero4;
+        for (int j = 0; j < 4; ++j) {
+            const int slot = (wu * 4 + j) * 64 + lane, row = slot >> 3, sp = slot & 7;
+            const int sidx = sp ^ ((row >> 1) & 7);
+            const u32x4* src;
+            if (W_ROWMAJOR) {
+                const int gn = min(n0 + row, p.N - 1);
+                src = Wg + (((long long)gn * p.ldw + k0) >> 2) + sidx;
+            } else {
+                src = Wg + ((long long)((k0 >> 4) + (sidx >> 2)) * p.Npad + n0 + row) * 4 + (sidx & 3);
             }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = t + 256 * i, kc = idx >> 9, rem = idx & 511;
-                rw[i] = Wg[((long long)((k0 >> 4) + kc) * p.Npad + n0) * 4 + rem];
-            }
-        }
-    };
-    auto store_stage = [&](int buf) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = t + 256 * i, row = idx >> 3, s = idx & 7;
-            s_tok[buf][swz(row, s)] = ra[i];
-        }
-        if (W_ROWMAJOR) {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = t + 256 * i, row = idx >> 3, s = idx & 7;
-                s_w[buf][swz(row, s)] = rw[i];
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int idx = t + 256 * i, kc = idx >> 9, rem = idx & 511, n = rem >> 2, q = rem & 3;
-                s_w[buf][swz(n, kc * 4 + q)] = rw[i];
-            }
+            __builtin_amdgcn_global_load_lds(src, &s_w[buf][(wu * 4 + j) * 64], 16, 0, 0);
         }
     };
 
-    load_stage(0);
-    store_stage(0);
+    issue_stage(0, 0);
     __syncthreads();
 
     const int i32 = lane & 31, h = lane >> 5;
     for (int kt = 0; kt < nk; ++kt) {
         const int buf = kt & 1;
-        if (kt + 1 < nk) load_stage(kt + 1);
+        if (kt + 1 < nk) issue_stage(kt + 1, buf ^ 1);
         const f16x8* st = reinterpret_cast<const f16x8*>(s_tok[buf]);
         const f16x8* sw = reinterpret_cast<const f16x8*>(s_w[buf]);
 #pragma unroll
         for (int kc = 0; kc < 2; ++kc) {
-            f16x8 ah[2], al[2], bh[2], bl[2];
+            f16x8 ah[4], al[4], bh[2], bl[2];
 #pragma unroll
-            for (int ft = 0; ft < 2; ++ft) {
-                const int row = wf * 64 + ft * 32 + i32;
+            for (int ft = 0; ft < 4; ++ft) {
+                const int row = wf * 128 + ft * 32 + i32;
                 ah[ft] = sw[swz(row, kc * 4 + 2 * h)];
                 al[ft] = sw[swz(row, kc * 4 + 2 * h + 1)];
             }
@@ -116,19 +100,18 @@ __global__ __launch_bounds__(256, 2) void gemm_f16x3_kernel(const GemmF16Args p)
                 bl[tt] = st[swz(row, kc * 4 + 2 * h + 1)];
             }
 #pragma unroll
-            for (int ft = 0; ft < 2; ++ft)
+            for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
                 for (int tt = 0; tt < 2; ++tt) mma3(ah[ft], al[ft], bh[tt], bl[tt], acc[ft][tt]);
         }
-        if (kt + 1 < nk) store_stage(buf ^ 1);
-        __syncthreads();
+        __syncthreads();  // drains this stage's DMA (vmcnt(0)) and fences the buffer swap
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
     float* C = p.C ? p.C + z * p.strideC : nullptr;
 #pragma unroll
-    for (int ft = 0; ft < 2; ++ft) {
-        const int fb = n0 + wf * 64 + ft * 32 + 16 * h;  // first of this lane's 16 consecutive features
+    for (int ft = 0; ft < 4; ++ft) {
+        const int fb = n0 + wf * 128 + ft * 32 + 16 * h;  // first of this lane's 16 consecutive features
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int tok = m0 + wt * 64 + tt * 32 + i32;
@@ -217,9 +200,9 @@ __global__ __launch_bounds__(256) void to_sh8_kernel(const float* __restrict__ i
 void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s) {
     dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, a.batch);
     if (a.w_rowmajor)
-        hipLaunchKernelGGL(gemm_f16x3_kernel<true>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gemm_f16x3_kernel<true>, grid, dim3(GT), 0, s, a);
     else
-        hipLaunchKernelGGL(gemm_f16x3_kernel<false>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL(gemm_f16x3_kernel<false>, grid, dim3(GT), 0, s, a);
 }
 
 void launch_to_sh8(const float* in, void* out, long long elems, hipStream_t s) {
