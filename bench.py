@@ -48,7 +48,7 @@ def algorithmic_flops(B):
     T = (K + K) * B  # tokens per step
     lin = lambda i, o: 2.0 * T * i * o
     f = {
-        "sp.conv1a": conv(1, 64, hw[0]), "sp.conv1b": conv(64, 64, hw[0]),
+        "sp.conv1a": conv(1, 64, hw[0]), "sp.conv1b": conv(64, 64, hw[0]), "sp.conv1ab": conv(1, 64, hw[0]) + conv(64, 64, hw[0]),
         "sp.conv2a": conv(64, 64, hw[1]), "sp.conv2b": conv(64, 64, hw[1]),
         "sp.conv3a": conv(64, 128, hw[2]), "sp.conv3b": conv(128, 128, hw[2]),
         "sp.conv4a": conv(128, 128, hw[3]), "sp.conv4b": conv(128, 128, hw[3]),

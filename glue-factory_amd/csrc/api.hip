@@ -591,7 +591,8 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
 
     const int H2 = H / 2, W2 = W / 2, H4 = H2 / 2, W4 = W2 / 2, hc = H4 / 2, wc = W4 / 2;
     const size_t n1 = (size_t)B * H * W, n2 = (size_t)B * H2 * W2, n4 = (size_t)B * H4 * W4, n8 = (size_t)B * hc * wc;
-    float* a1 = h->buf("sp.a1", n1 * 64);
+    const bool want_a1 = h->precision != MG_PREC_F16X3 || h->taps.count("sp.conv1a");
+    float* a1 = h->buf("sp.a1", want_a1 ? n1 * 64 : 64);
     float* p1 = h->buf("sp.p1", n2 * 64);
     float* a2 = h->buf("sp.a2", n2 * 64);
     float* p2 = h->buf("sp.p2", n4 * 64);
@@ -607,12 +608,15 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
     if (!a1 || !p1 || !a2 || !p2 || !a3 || !p3 || !a4 || !f4 || !cP || !cD || !lg || !dd || !heat) return fail(MG_ERR_HIP, "workspace allocation failed");
 
     const bool f16 = h->precision == MG_PREC_F16X3;
-    {
+    // f16x3: conv1a is recomputed inside conv1b's tile loop (the 64-channel full-resolution map never
+    // reaches HBM) unless a test asked to see it.
+    const bool fuse1 = f16 && !h->taps.count("sp.conv1a");
+    Conv1aArgs c1;
+    c1.image = image; c1.B = B; c1.C = C; c1.H = H; c1.W = W;
+    c1.w = h->c1a_w; c1.bias = h->c1a_b; c1.post_scale = h->c1a_ps; c1.post_shift = h->c1a_pt; c1.out = a1;
+    if (!fuse1) {
         ProfScope ps(h, s, "sp.conv1a");
-        Conv1aArgs a;
-        a.image = image; a.B = B; a.C = C; a.H = H; a.W = W;
-        a.w = h->c1a_w; a.bias = h->c1a_b; a.post_scale = h->c1a_ps; a.post_shift = h->c1a_pt; a.out = a1;
-        if (f16) launch_conv1a_sh8(a, s); else launch_conv1a(a, s);
+        if (f16) launch_conv1a_sh8(c1, s); else launch_conv1a(c1, s);
     }
     if (int rc = tap_copy(h, "sp.conv1a", a1, n1 * 64, s)) return rc;
     struct Step { const char* name; int layer; const float* in; float* out; int Hh, Ww, pool; };
@@ -621,9 +625,14 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
         {"sp.conv3a", 3, p2, a3, H4, W4, 0}, {"sp.conv3b", 4, a3, p3, H4, W4, 1}, {"sp.conv4a", 5, p3, a4, hc, wc, 0},
         {"sp.conv4b", 6, a4, f4, hc, wc, 0}, {"sp.convPa", 7, f4, cP, hc, wc, 0}, {"sp.convDa", 8, f4, cD, hc, wc, 0}};
     for (const Step& st : steps) {
-        ProfScope ps(h, s, st.name);
+        ProfScope ps(h, s, (fuse1 && st.layer == 0) ? "sp.conv1ab" : st.name);
         const ConvLayer& L = h->conv[st.layer];
-        if (f16) {
+        if (fuse1 && st.layer == 0) {
+            ConvF16Args a;
+            a.Wt = L.Wh; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
+            a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = 1; a.relu = 1;
+            launch_conv1ab_f16x3(a, c1, s);
+        } else if (f16) {
             ConvF16Args a;
             a.in = st.in; a.Wt = L.Wh; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
             a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = st.pool; a.relu = 1;

@@ -196,6 +196,233 @@ __global__ __launch_bounds__(CT, 2) void conv3x3_f16x3_kernel(const ConvF16Args 
     }
 }
 
+// conv1a + conv1b + 2x2 max-pool in one kernel (superpoint.py:209-211): the 64-channel full-resolution
+// map of conv1a (78.6 MB per VGA image) never exists in HBM.  Per 16-channel chunk the conv1a outputs of
+// the 18x34 halo tile are recomputed from a 20x36 gray tile in LDS (VALU, weights in SGPRs: every wave
+// handles one 8-channel group so the filter taps are wave-uniform) and written as SH8 pieces straight
+// into the double-buffered conv1b input tile.  Waves 0-3 produce the next chunk and then multiply the
+// current one, waves 4-7 do it in the opposite order: SIMD partners (w, w+4) are always in opposite
+// phases, so the VALU work of one runs under the MFMAs of the other.
+__global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args p, const Conv1aArgs c1) {
+    constexpr int WY = 4, WX = 2;
+    constexpr int TH = 4 * WY, TW = 16 * WX;
+    constexpr int PW = ((TW + 2 + 7) / 16) * 16 + 8;
+    constexpr int NPIX = (TH + 2) * (TW + 2);
+    constexpr int NWT = (9 * 64 * 4 + CT - 1) / CT;
+    constexpr int GH = TH + 4, GW = TW + 4, GP = GW + 1;
+    __shared__ u32x4 s_in[2][(TH + 2) * PW * 4];
+    __shared__ u32x4 s_w[9 * 64 * 4];
+    __shared__ float s_g[GH * GP];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const int tiles_x = (p.W + TW - 1) / TW;
+    const int y0 = (blockIdx.x / tiles_x) * TH, x0 = (blockIdx.x % tiles_x) * TW;
+    const int n0 = blockIdx.y * 64;
+    const int b = blockIdx.z;
+    const u32x4* wt = reinterpret_cast<const u32x4*>(p.Wt);
+
+    // gray tile (RGB -> gray as superpoint.py:204-206), zero outside the image
+    {
+        const long long HW = (long long)c1.H * c1.W;
+        const float* img = c1.image + (long long)b * c1.C * HW;
+        for (int i = t; i < GH * GW; i += CT) {
+            const int gy = i / GW, gx = i - gy * GW;
+            const int yy = y0 + gy - 2, xx = x0 + gx - 2;
+            float v = 0.f;
+            if (yy >= 0 && yy < c1.H && xx >= 0 && xx < c1.W) {
+                const long long o = (long long)yy * c1.W + xx;
+                if (c1.C == 3)
+                    v = __fadd_rn(__fadd_rn(__fmul_rn(img[o], 0.299f), __fmul_rn(img[HW + o], 0.587f)), __fmul_rn(img[2 * HW + o], 0.114f));
+                else
+                    v = img[o];
+            }
+            s_g[gy * GP + gx] = v;
+        }
+    }
+
+    u32x4 rwt[NWT];
+    auto load_w = [&](int c) {
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int idx = t + CT * i, row = idx >> 2, q = idx & 3, tap = row >> 6, n = row & 63;
+            rwt[i] = (idx < 9 * 64 * 4) ? wt[((long long)(c * 9 + tap) * p.CoutPad + n0 + n) * 4 + q] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_w = [&]() {
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int idx = t + CT * i, row = idx >> 2, q = idx & 3;
+            if (idx < 9 * 64 * 4) s_w[row * 4 + (q ^ ((row >> 2) & 3))] = rwt[i];
+        }
+    };
+    // conv1a for chunk c (channels 16c .. 16c+15) over the halo tile -> s_in[buf].  The 8 channels of a
+    // wave are done in two halves of 4 so that their 36 taps + bias/affine stay in SGPRs.
+    auto produce = [&](int c, int buf) {
+        const int gg = wu & 1;              // 8-channel group of this wave (uniform)
+        const int ch0 = c * 16 + gg * 8;
+        const int hp0 = (wu >> 1) * 64 + lane;
+        f32x8 o8[3];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            float wk[4][9], bs[4], psc[4], psh[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int ch = ch0 + half * 4 + j;
+#pragma unroll
+                for (int k = 0; k < 9; ++k) wk[j][k] = c1.w[ch * 9 + k];
+                bs[j] = c1.bias[ch];
+                psc[j] = c1.post_scale ? c1.post_scale[ch] : 1.f;
+                psh[j] = c1.post_shift ? c1.post_shift[ch] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 3; ++i) {
+                const int hp = min(hp0 + 256 * i, NPIX - 1);
+                const int py = hp / (TW + 2), px = hp - py * (TW + 2);
+                float g[9];
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) g[ky * 3 + kx] = s_g[(py + ky) * GP + px + kx];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    float a = 0.f;
+#pragma unroll
+                    for (int k = 0; k < 9; ++k) a = fmaf(wk[j][k], g[k], a);
+                    a += bs[j];
+                    a = fmaxf(a, 0.f);
+                    if (c1.post_scale) a = __fadd_rn(__fmul_rn(a, psc[j]), psh[j]);
+                    o8[i][half * 4 + j] = a;
+                }
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int hp = hp0 + 256 * i;
+            if (hp >= NPIX) continue;
+            const int py = hp / (TW + 2), px = hp - py * (TW + 2);
+            const int yy = y0 + py - 1, xx = x0 + px - 1;
+            const bool inside = yy >= 0 && yy < c1.H && xx >= 0 && xx < c1.W;
+            f16x8 hi, lo;
+            split8(inside ? o8[i] : f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, hi, lo);
+            const int P = py * PW + px, sw4 = (P >> 2) & 3;
+            s_in[buf][P * 4 + ((2 * gg) ^ sw4)] = __builtin_bit_cast(u32x4, hi);
+            s_in[buf][P * 4 + ((2 * gg + 1) ^ sw4)] = __builtin_bit_cast(u32x4, lo);
+        }
+    };
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int wy0 = (wave / WX) * 4, wx0 = (wave % WX) * 16;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
+    const int wsw = (i32 >> 2) & 3;
+    const int a_hi = i32 * 4 + ((2 * h) ^ wsw), a_lo = i32 * 4 + ((2 * h + 1) ^ wsw);
+
+    auto multiply = [&](int buf) {
+        const f16x8* si = reinterpret_cast<const f16x8*>(s_in[buf]);
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w);
+#pragma unroll 1
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                f16x8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int P = P0 + (2 * nt + ky) * PW + kx;
+                    const int sw4 = (P >> 2) & 3;
+                    bh[nt] = si[P * 4 + ((2 * h) ^ sw4)];
+                    bl[nt] = si[P * 4 + ((2 * h + 1) ^ sw4)];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int ro = ((ky * 3 + kx) * 64 + mt * 32) * 4;
+                    ah[mt] = sw[ro + a_hi];
+                    al[mt] = sw[ro + a_lo];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) mma3(ah[mt], al[mt], bh[nt], bl[nt], acc[mt][nt]);
+            }
+        }
+    };
+
+    const int nchunks = 4;  // conv1a has 64 output channels
+    load_w(0);
+    __syncthreads();          // gray tile ready
+    produce(0, 0);
+    store_w();
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        if (c + 1 < nchunks) load_w(c + 1);
+        if (wu < 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
+        multiply(buf);
+        if (wu >= 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
+        __syncthreads();      // everyone is done with s_w and s_in[buf]
+        if (c + 1 < nchunks) {
+            store_w();
+            __syncthreads();
+        }
+    }
+
+    // ---- epilogue: identical to conv3x3_f16x3_kernel with pool = 1, SH8 output ----------------------
+    const int Ho = p.H / 2, Wo = p.W / 2;
+    const int blk = i32 >> 2;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int cb = n0 + mt * 32;
+        float bias[16], ps[16], pt[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = cb + 8 * (r >> 2) + 4 * h + (r & 3);
+            const bool ok = ch < p.Cout;
+            bias[r] = ok ? p.bias[ch] : 0.f;
+            ps[r] = (p.post_scale && ok) ? p.post_scale[ch] : 1.f;
+            pt[r] = (p.post_shift && ok) ? p.post_shift[ch] : 0.f;
+        }
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[mt][nt][r] + bias[r];
+                x = fmaxf(x, 0.f);
+                if (p.post_scale) x = __fadd_rn(__fmul_rn(x, ps[r]), pt[r]);
+                x = fmaxf(x, dpp_quad_xor1(x));
+                x = fmaxf(x, dpp_quad_xor2(x));
+                v[r] = x;
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                half_swap(v[e], v[8 + e]);
+                half_swap(v[4 + e], v[12 + e]);
+            }
+            const f32x8 g0 = {v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]};
+            const f32x8 g1 = {v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]};
+            const int oy = (y0 + wy0 + 2 * nt) >> 1;
+            const int ox = ((x0 + wx0) >> 1) + blk;
+            const bool ok = ((i32 & 3) == 0) && oy < Ho && ox < Wo;
+            const int ch0 = cb + 16 * h;
+            if (ok && ch0 < p.Cout) {
+                const long long pix = ((long long)b * Ho + oy) * Wo + ox;
+                f16x8 hi0, lo0, hi1, lo1;
+                split8(g0, hi0, lo0);
+                split8(g1, hi1, lo1);
+                f16x8* o = reinterpret_cast<f16x8*>(p.out) + (pix * p.Cout + ch0) / 4;
+                o[0] = hi0; o[1] = lo0; o[2] = hi1; o[3] = lo1;
+            }
+        }
+    }
+}
+
 // conv1a writing SH8: 8 lanes per pixel, 8 output channels each (one hi + one lo 16-byte piece).
 __global__ __launch_bounds__(256) void conv1a_sh8_kernel(const Conv1aArgs p) {
     __shared__ float s_w[64 * 9 + 64 * 3];
@@ -266,6 +493,11 @@ void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
         dim3 grid(((a.H + 31) / 32) * ((a.W + 15) / 16), nslices, a.B);
         hipLaunchKernelGGL((conv3x3_f16x3_kernel<8, 1>), grid, dim3(CT), 0, s, a);
     }
+}
+
+void launch_conv1ab_f16x3(const ConvF16Args& a, const Conv1aArgs& c1, hipStream_t s) {
+    dim3 grid(((a.H + 15) / 16) * ((a.W + 31) / 32), (a.Cout + 63) / 64, a.B);
+    hipLaunchKernelGGL(conv1ab_f16x3_kernel, grid, dim3(CT), 0, s, a, c1);
 }
 
 void launch_conv1a_sh8(const Conv1aArgs& a, hipStream_t s) {

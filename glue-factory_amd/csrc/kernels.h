@@ -77,6 +77,8 @@ struct ConvF16Args {
 };
 void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s);
 void launch_conv1a_sh8(const Conv1aArgs& a, hipStream_t s);
+// conv1a + conv1b + pool fused (input = the image itself; a.in is unused)
+void launch_conv1ab_f16x3(const ConvF16Args& a, const Conv1aArgs& c1, hipStream_t s);
 
 // ---- gemm_f16.hip : the same GEMM on the f16 MFMA, SH8 operands --------------------------------
 struct GemmF16Args {
