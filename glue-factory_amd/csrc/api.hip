@@ -79,6 +79,7 @@ struct LgBlock {
     LinLayer proj;  // self: Wqkv (q|k|v rows), cross: [to_qk ; to_v]
     LinLayer out;   // out_proj / to_out
     LinLayer ffn0, ffn3;
+    LinLayer ffn0f;  // ffn.0 with the out-projection folded in (consumes cat[x, ctx])
     float *ln_g = nullptr, *ln_b = nullptr;
 };
 
@@ -316,6 +317,34 @@ int prepare_sp(mg_context* h, int variant) {
     return 0;
 }
 
+// ffn.0 consumes cat[x, message] with message = out(ctx) (lightglue.py:156-157, :213-214); the message
+// is used nowhere else, so the out-projection is folded into the second half of ffn.0 at upload:
+//   ffn0(cat[x, ctx Wo^T + bo]) = x W0a^T + ctx (W0b Wo)^T + (b0 + W0b bo)      (products in fp64)
+// which removes one GEMM + one (tokens,256) round trip per block.  `ffn0f` is that folded layer.
+int prep_ffn0_folded(mg_context* h, const std::string& p, const std::string& outname, LinLayer* L) {
+    const HostTensor *w0, *b0, *wo, *bo;
+    if (int rc = need(h, 1, p + ".ffn.0.weight", {512, 512}, &w0)) return rc;
+    if (int rc = need(h, 1, p + ".ffn.0.bias", {512}, &b0)) return rc;
+    if (int rc = need(h, 1, p + "." + outname + ".weight", {256, 256}, &wo)) return rc;
+    if (int rc = need(h, 1, p + "." + outname + ".bias", {256}, &bo)) return rc;
+    std::vector<float> W((size_t)512 * 512), bias(512);
+    for (int n = 0; n < 512; ++n) {
+        const float* w0n = w0->data.data() + (size_t)n * 512;
+        for (int k = 0; k < 256; ++k) W[(size_t)n * 512 + k] = w0n[k];
+        for (int k = 0; k < 256; ++k) {
+            double acc = 0.0;
+            for (int j = 0; j < 256; ++j) acc += (double)w0n[256 + j] * (double)wo->data[(size_t)j * 256 + k];
+            W[(size_t)n * 512 + 256 + k] = (float)acc;
+        }
+        double bb = b0->data[n];
+        for (int j = 0; j < 256; ++j) bb += (double)w0n[256 + j] * (double)bo->data[j];
+        bias[n] = (float)bb;
+    }
+    std::vector<const float*> rows(512);
+    for (int n = 0; n < 512; ++n) rows[n] = W.data() + (size_t)n * 512;
+    return prep_linear_rows(h, rows, bias, 512, L);
+}
+
 int prep_ffn(mg_context* h, const std::string& p, LgBlock* blk) {
     if (int rc = prep_linear(h, 1, p + ".ffn.0", 512, 512, &blk->ffn0)) return rc;
     if (int rc = prep_linear(h, 1, p + ".ffn.3", 256, 512, &blk->ffn3)) return rc;
@@ -350,6 +379,7 @@ int prepare_lg(mg_context* h, int n_layers) {
         if (int rc = prep_linear_rows(h, rows, bias, 256, &h->lg_self[i].proj)) return rc;
         if (int rc = prep_linear(h, 1, ps + ".out_proj", 256, 256, &h->lg_self[i].out)) return rc;
         if (int rc = prep_ffn(h, ps, &h->lg_self[i])) return rc;
+        if (int rc = prep_ffn0_folded(h, ps, "out_proj", &h->lg_self[i].ffn0f)) return rc;
         // cross: one GEMM for [to_qk ; to_v]
         const HostTensor *wq, *bq, *wv, *bv;
         if (int rc = need(h, 1, pc + ".to_qk.weight", {256, 256}, &wq)) return rc;
@@ -367,6 +397,7 @@ int prepare_lg(mg_context* h, int n_layers) {
         if (int rc = prep_linear_rows(h, rows2, bias2, 256, &h->lg_cross[i].proj)) return rc;
         if (int rc = prep_linear(h, 1, pc + ".to_out", 256, 256, &h->lg_cross[i].out)) return rc;
         if (int rc = prep_ffn(h, pc, &h->lg_cross[i])) return rc;
+        if (int rc = prep_ffn0_folded(h, pc, "to_out", &h->lg_cross[i].ffn0f)) return rc;
     }
     const std::string pa = "log_assignment." + std::to_string(n_layers - 1);
     if (int rc = prep_linear(h, 1, pa + ".final_proj", 256, 256, &h->final_proj)) return rc;
@@ -738,8 +769,8 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         {
             ProfScope ps(h, s, "lg.gemm.ffn0");
             if (f16) {
-                GemmF16Args g = lin_args_f16(blk.ffn0, XS, 256, (int)T);
-                g.A1 = MSG; g.lda1 = 256; g.ksplit = 256;
+                GemmF16Args g = lin_args_f16(blk.ffn0f, XS, 256, (int)T);
+                g.A1 = CTX; g.lda1 = 256; g.ksplit = 256;
                 g.C = HID; g.ldc = 512;
                 launch_gemm_f16x3(g, s);
             } else {
@@ -796,12 +827,9 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         }
     };
     auto outproj = [&](const LgBlock& blk) {
+        if (f16) return;  // folded into ffn.0 (prep_ffn0_folded)
         ProfScope ps(h, s, "lg.gemm.out");
-        if (f16) {
-            GemmF16Args g = lin_args_f16(blk.out, CTX, 256, (int)T);
-            g.Cs = MSG; g.ldcs = 256;
-            launch_gemm_f16x3(g, s);
-        } else {
+        {
             GemmArgs g = lin_args(blk.out, CTX, 256, (int)T, MSG, 256);
             launch_gemm(g, s);
         }
@@ -809,14 +837,16 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
 
     for (int i = 0; i < conf->n_layers; ++i) {
         const LgBlock& sb = h->lg_self[i];
-        proj(sb, "lg.gemm.qkv", 768, 0.125f, true);
+        // f16x3: log2(e) is folded into the logit scale so the attention kernel uses bare v_exp_f32
+        proj(sb, "lg.gemm.qkv", 768, f16 ? 0.125f * 1.4426950408889634f : 0.125f, true);
         attend("lg.attn.self", 768, 256, 512, 0);
         outproj(sb);
         ffn(sb);
         if (int rc = tap_copy(h, "lg.self" + std::to_string(i), X, T * 256, s)) return rc;
 
         const LgBlock& cb = h->lg_cross[i];
-        proj(cb, "lg.gemm.qkv_cross", 512, 0.35355339059327373f, false);  // (dim_head^-0.5)^0.5, lightglue.py:200
+        // (dim_head^-0.5)^0.5 on both sides, lightglue.py:200 (x sqrt(log2 e) each in f16x3 mode)
+        proj(cb, "lg.gemm.qkv_cross", 512, f16 ? 0.35355339059327373f * 1.2011224087864498f : 0.35355339059327373f, false);
         attend("lg.attn.cross", 512, 0, 256, 1);
         outproj(cb);
         ffn(cb);
