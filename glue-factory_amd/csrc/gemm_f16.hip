@@ -20,6 +20,23 @@ constexpr int TN = 256, TM = 256, BK = 32, GT = 512;  // 8 waves: 2 (features) x
 
 __device__ __forceinline__ int swz(int row, int s) { return row * 8 + (s ^ ((row >> 1) & 7)); }
 
+// Tile that straddles N (the 65-channel detector head): element-wise, fp32 output only (no rotary / SH8
+// at a ragged edge).  Kept out of line so the hot epilogue stays small.
+__device__ __attribute__((noinline)) void epilogue_ragged(const GemmF16Args& p, float* C, f32x16 w, int fb, long long tokc, bool tok_ok) {
+    if (!tok_ok || !C) return;
+    for (int j = 0; j < 16; ++j) {
+        const int f = fb + j;
+        if (f >= p.N) break;
+        float x = w[j];
+        if (p.bias) x += p.bias[f];
+        if (p.relu) x = fmaxf(x, 0.f);
+        if (p.post_scale) x = __fadd_rn(__fmul_rn(x, p.post_scale[f]), p.post_shift[f]);
+        if (f < p.scale_cols) x *= p.scale;
+        if (p.residual) x += p.residual[tokc * p.ldr + f];
+        C[tokc * p.ldc + f] = x;
+    }
+}
+
 template <bool W_ROWMAJOR>
 __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
     __shared__ u32x4 s_tok[2][TM * 8];
@@ -108,14 +125,23 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    // All tile-level decisions are made on wave-uniform values (block / wave indices), so the fast
+    // path is straight-line code with 16-byte loads and stores; only a tile that straddles N (the
+    // 65-channel detector head) takes the element-wise path.
+    asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> inline-asm permlane reads
     float* C = p.C ? p.C + z * p.strideC : nullptr;
+    const int wfu = wu >> 2;
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
-        const int fb = n0 + wf * 128 + ft * 32 + 16 * h;  // first of this lane's 16 consecutive features
+        const int fbase = n0 + wfu * 128 + ft * 32;  // uniform
+        const int fb = fbase + 16 * h;               // first of this lane's 16 consecutive features
+        const bool full = fbase + 32 <= p.N;
+        if (fbase >= p.N) continue;
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
             const int tok = m0 + wt * 64 + tt * 32 + i32;
             const bool tok_ok = tok < p.M;
+            const long long tokc = tok_ok ? tok : 0;
             f32x16 w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -124,59 +150,75 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
                 half_swap(a1, b1);
                 w[e] = a0; w[4 + e] = b0; w[8 + e] = a1; w[12 + e] = b1;
             }
+            if (full) {
+                if (p.bias) {
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int f = fb + j;
-                if (p.bias && f < p.N) w[j] += p.bias[f];
-            }
-            if (p.rotary_cols > 0 && fb < p.rotary_cols) {  // lightglue.py:36-43, pairs (2i, 2i+1)
-                const float* e = p.enc + (long long)(tok_ok ? tok : 0) * 64;
-#pragma unroll
-                for (int j = 0; j < 16; j += 2) {
-                    const int fq = ((fb + j) & 63) >> 1;
-                    const float c = e[fq], s = e[fq + 32];
-                    const float xe = w[j], xo = w[j + 1];
-                    w[j] = __fadd_rn(__fmul_rn(xe, c), __fmul_rn(-xo, s));
-                    w[j + 1] = __fadd_rn(__fmul_rn(xo, c), __fmul_rn(xe, s));
+                    for (int j = 0; j < 16; j += 4) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + fb + j);
+                        w[j] += bv.x; w[j + 1] += bv.y; w[j + 2] += bv.z; w[j + 3] += bv.w;
+                    }
                 }
-            }
+                if (fbase < p.rotary_cols) {  // lightglue.py:36-43, pairs (2i, 2i+1); 8 frequencies per lane
+                    const float* er = p.enc + tokc * 64 + ((fb & 63) >> 1);
+                    const f32x4 c0 = *reinterpret_cast<const f32x4*>(er), c1 = *reinterpret_cast<const f32x4*>(er + 4);
+                    const f32x4 s0 = *reinterpret_cast<const f32x4*>(er + 32), s1 = *reinterpret_cast<const f32x4*>(er + 36);
+                    const float cs[8] = {c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w};
+                    const float sn[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
 #pragma unroll
-            for (int j = 0; j < 16; ++j) {
-                const int f = fb + j;
-                float x = w[j];
-                if (p.relu) x = fmaxf(x, 0.f);
-                if (p.post_scale && f < p.N) x = __fadd_rn(__fmul_rn(x, p.post_scale[f]), p.post_shift[f]);
-                if (f < p.scale_cols) x *= p.scale;
-                w[j] = x;
-            }
-            if (!tok_ok || fb >= p.N) continue;
-            if (p.residual) {
-                const float* rs = p.residual + (long long)tok * p.ldr + fb;
-#pragma unroll
-                for (int j = 0; j < 16; j += 4) {
-                    const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + j);
-                    w[j] += rv.x; w[j + 1] += rv.y; w[j + 2] += rv.z; w[j + 3] += rv.w;
+                    for (int j = 0; j < 8; ++j) {
+                        const float xe = w[2 * j], xo = w[2 * j + 1];
+                        w[2 * j] = __fadd_rn(__fmul_rn(xe, cs[j]), __fmul_rn(-xo, sn[j]));
+                        w[2 * j + 1] = __fadd_rn(__fmul_rn(xo, cs[j]), __fmul_rn(xe, sn[j]));
+                    }
                 }
-            }
-            if (C) {
-                float* o = C + (long long)tok * p.ldc + fb;
-                if (fb + 16 <= p.N && (p.ldc & 3) == 0) {
+                if (p.relu) {
 #pragma unroll
-                    for (int j = 0; j < 16; j += 4) *reinterpret_cast<f32x4*>(o + j) = f32x4{w[j], w[j + 1], w[j + 2], w[j + 3]};
-                } else {
-#pragma unroll
-                    for (int j = 0; j < 16; ++j)
-                        if (fb + j < p.N) o[j] = w[j];
+                    for (int j = 0; j < 16; ++j) w[j] = fmaxf(w[j], 0.f);
                 }
-            }
-            if (p.Cs) {
-                const f32x8 g0 = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
-                const f32x8 g1 = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]};
-                f16x8 hi0, lo0, hi1, lo1;
-                split8(g0, hi0, lo0);
-                split8(g1, hi1, lo1);
-                f16x8* o = reinterpret_cast<f16x8*>(p.Cs) + (((long long)tok * p.ldcs + fb) >> 2) + z * (p.strideCs >> 2);
-                o[0] = hi0; o[1] = lo0; o[2] = hi1; o[3] = lo1;
+                if (p.post_scale) {
+#pragma unroll
+                    for (int j = 0; j < 16; j += 4) {
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(p.post_scale + fb + j);
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(p.post_shift + fb + j);
+                        w[j] = __fadd_rn(__fmul_rn(w[j], a.x), c.x); w[j + 1] = __fadd_rn(__fmul_rn(w[j + 1], a.y), c.y);
+                        w[j + 2] = __fadd_rn(__fmul_rn(w[j + 2], a.z), c.z); w[j + 3] = __fadd_rn(__fmul_rn(w[j + 3], a.w), c.w);
+                    }
+                }
+                if (fbase < p.scale_cols) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) w[j] *= p.scale;
+                }
+                if (tok_ok) {
+                    if (p.residual) {
+                        const float* rs = p.residual + tokc * p.ldr + fb;
+#pragma unroll
+                        for (int j = 0; j < 16; j += 4) {
+                            const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + j);
+                            w[j] += rv.x; w[j + 1] += rv.y; w[j + 2] += rv.z; w[j + 3] += rv.w;
+                        }
+                    }
+                    if (C) {
+                        float* o = C + tokc * p.ldc + fb;
+                        if ((p.ldc & 3) == 0) {
+#pragma unroll
+                            for (int j = 0; j < 16; j += 4) *reinterpret_cast<f32x4*>(o + j) = f32x4{w[j], w[j + 1], w[j + 2], w[j + 3]};
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 16; ++j) o[j] = w[j];
+                        }
+                    }
+                    if (p.Cs) {
+                        const f32x8 g0 = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
+                        const f32x8 g1 = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]};
+                        f16x8 hi0, lo0, hi1, lo1;
+                        split8(g0, hi0, lo0);
+                        split8(g1, hi1, lo1);
+                        f16x8* o = reinterpret_cast<f16x8*>(p.Cs) + ((tokc * p.ldcs + fb) >> 2) + z * (p.strideCs >> 2);
+                        o[0] = hi0; o[1] = lo0; o[2] = hi1; o[3] = lo1;
+                    }
+                }
+            } else {
+                epilogue_ragged(p, C, w, fb, tokc, tok_ok);
             }
         }
     }
