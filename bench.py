@@ -28,7 +28,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 H, W, K, PAIRS = 480, 640, 1024, 32
-PEAK_F32_MFMA = 157.3  # TFLOP/s, MI355X_MICROARCH.md (v_mfma_f32_32x32x2_f32 rate)
+# TFLOP/s, MI355X_MICROARCH.md: dense MFMA peak of the dtype the matrix pipe is fed with
+PEAK = {"f32": 157.3,      # v_mfma_f32_32x32x2_f32
+        "f16x3": 2500.0}   # v_mfma_f32_32x32x16_f16; every algorithmic product costs 3 MFMA products (hi.hi + hi.lo + lo.hi)
 
 
 def synthetic_images(n, seed):
@@ -48,7 +50,8 @@ def algorithmic_flops(B):
     T = (K + K) * B  # tokens per step
     lin = lambda i, o: 2.0 * T * i * o
     f = {
-        "sp.conv1a": conv(1, 64, hw[0]), "sp.conv1b": conv(64, 64, hw[0]), "sp.conv1ab": conv(1, 64, hw[0]) + conv(64, 64, hw[0]),
+        "sp.conv1a": conv(1, 64, hw[0]), "sp.conv1b": conv(64, 64, hw[0]),
+        "sp.conv1ab": conv(1, 64, hw[0]) + conv(64, 64, hw[0]),  # conv1a recomputed inside conv1b's tiles (f16x3 mode)
         "sp.conv2a": conv(64, 64, hw[1]), "sp.conv2b": conv(64, 64, hw[1]),
         "sp.conv3a": conv(64, 128, hw[2]), "sp.conv3b": conv(128, 128, hw[2]),
         "sp.conv4a": conv(128, 128, hw[3]), "sp.conv4b": conv(128, 128, hw[3]),
@@ -97,6 +100,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--pairs", type=int, default=PAIRS, help="pairs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
+                    help="f32: fp32-input MFMA; f16x3: split-fp16 operands on the f16 MFMA (default, fp32-class accuracy)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -117,8 +122,9 @@ def main():
     B = args.pairs
     pipe = TwoViewPipeline({
         "extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": K, "nms_radius": 3,
-                      "detection_threshold": 0.0, "remove_borders": 4, "force_num_keypoints": True, "sync_free": True},
-        "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1},
+                      "detection_threshold": 0.0, "remove_borders": 4, "force_num_keypoints": True, "sync_free": True,
+                      "precision": args.precision},
+        "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "precision": args.precision},
     }).eval()
     pipe.extractor.load_state_dict(O.make_sp_weights(0))
     pipe.matcher.load_state_dict(O.make_lg_weights(7, final_gain=8.0, match_bias=2.0))
@@ -181,6 +187,14 @@ def main():
         kernels = {k: {"ms_per_step": round(v[0] / args.steps, 4), "launches_per_step": v[1] // args.steps,
                        "tflops": round(flops[k] * (v[1] / args.steps) / (v[0] / args.steps * 1e-3) / 1e12, 2) if k in flops else None}
                    for k, v in sorted(prof.items(), key=lambda kv: -kv[1][0])}
+        # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 PMC passes of this same
+        # command (profiles/summarize_pmc.py; FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), not live
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", f"r01_b_{args.precision}_hbm_traffic.json")
+        if os.path.exists(tpath) and B == PAIRS:
+            tj = json.load(open(tpath))
+            if dom in tj:
+                traffic, traffic_src = tj[dom]["hbm_bytes_per_launch"], os.path.relpath(tpath, ROOT)
         res = {
             "metric": "image-pairs/sec SP+LightGlue (VGA, 1024 kpts) at 1/2/4/8 MI355X",
             "value": round(world * B * args.steps / dt, 3),
@@ -192,12 +206,16 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.precision,
             "data": "synthetic",
             "config": {"workload": f"SuperPoint + LightGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[1])",
-                       "pairs_per_gpu": B, "global_pairs": B * world, "parallelism": f"dp{world}", "matches_per_step_rank0": nvalid},
-            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK_F32_MFMA, "unit": "TFLOP/s",
-                         "frac": round(achieved / PEAK_F32_MFMA, 4), "traffic": None,
+                       "pairs_per_gpu": B, "global_pairs": B * world, "parallelism": f"dp{world}", "matches_per_step_rank0": nvalid,
+                       "arithmetic": ("fp32 storage, fp32-input MFMA, fp32 accumulate" if args.precision == "f32" else
+                                      "fp32-equivalent split-fp16 storage (hi+lo), f16 MFMA x3 products, fp32 accumulate")},
+            "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
+                         "frac": round(achieved / PEAK[args.precision], 4), "traffic": traffic, "traffic_source": traffic_src,
+                         "mfma_products_per_flop": 1 if args.precision == "f32" else 3,
+                         "executed_frac": round(achieved * (1 if args.precision == "f32" else 3) / PEAK[args.precision], 4),
                          "avg_launch_ms": round(avg_ms, 4), "algorithmic_flops_per_launch": flops[dom],
                          "kernel_time_share": round(prof[dom][0] / total_ms, 4)},
             "kernels": kernels,
