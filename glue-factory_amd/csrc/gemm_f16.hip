@@ -2,23 +2,27 @@
 //
 // Serves the Linear layers of LightGlue and SuperPoint's 1x1 heads in MG_PREC_F16X3 mode.  Re-cut for
 // the 16x faster pipe: a 256x256 tile (8 waves x 128 features x 64 tokens, K in stages of 32,
-// double-buffered 128 KB of LDS, one workgroup per CU) -- at this MFMA rate the 128x128 tile of gemm.hip
+// 144 KB of LDS rings, one workgroup per CU) -- at this MFMA rate the 128x128 tile of gemm.hip
 // is bound by L2->LDS traffic (42 B/clk/CU at full rate); 256x256 halves the bytes per MFMA:
-//   * both operands arrive SH8, so a stage row is 128 contiguous bytes = eight 16-byte pieces, moved
-//     to LDS by LDS-DMA (global_load_lds) with the piece index XOR (row>>1)&7 applied on the source
-//     side -> no ds_write traffic, and every fragment ds_read_b128 is conflict-free;
+//   * both operands arrive SH8, so a 16-deep stage row is 64 contiguous bytes = four 16-byte pieces,
+//     moved to LDS by LDS-DMA (global_load_lds) with the piece index XOR (row>>2)&3 applied on the
+//     source side -> no ds_write traffic, every fragment ds_read_b128 conflict-free; the token stream
+//     (HBM) and the weight stream (L2) are issued by different waves into rings of their own depth;
 //   * the weight tile is the A operand (rows = features) and the token tile the B operand (lanes), so a
 //     lane owns one token: after one v_permlane32_swap per register pair it holds 16 consecutive features
 //     -- rotary pairs are adjacent registers (no shuffle), the residual / fp32 store is 64 contiguous
 //     bytes, and the SH8 copy for the next MFMA consumer is produced in the same epilogue.
+#include <cstdlib>
+
 #include "common.h"
 #include "kernels.h"
 
 namespace {
 
-constexpr int TN = 256, TM = 256, BK = 32, GT = 512;  // 8 waves: 2 (features) x 4 (tokens), each 128 x 64
+constexpr int TN = 256, TM = 256, BK = 16, GT = 512;  // 8 waves: 2 (features) x 4 (tokens), each 128 x 64
+constexpr int TSLOTS = 6, WSLOTS = 3;  // LDS rings: token stages (HBM) run 5 ahead, weight stages (L2) 2 ahead
 
-__device__ __forceinline__ int swz(int row, int s) { return row * 8 + (s ^ ((row >> 1) & 7)); }
+__device__ __forceinline__ int swz(int row, int q) { return row * 4 + (q ^ ((row >> 2) & 3)); }  // 64-byte rows
 
 // Tile that straddles N (the 65-channel detector head): element-wise, fp32 output only (no rotary / SH8
 // at a ragged edge).  Kept out of line so the hot epilogue stays small.
@@ -39,12 +43,21 @@ __device__ __attribute__((noinline)) void epilogue_ragged(const GemmF16Args& p, 
 
 template <bool W_ROWMAJOR>
 __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
-    __shared__ u32x4 s_tok[2][TM * 8];
-    __shared__ u32x4 s_w[2][TN * 8];
+    // ONE LDS array (a second __shared__ object next to LDS-DMA staging makes hipcc drain vmcnt before
+    // every fragment read): [token ring: 6 x 256 rows x 64 B][weight ring: 3 x 256 rows x 64 B] = 144 KB
+    __shared__ u32x4 s_ring[(TSLOTS * TM + WSLOTS * TN) * 4];
+    u32x4* const s_tokr = s_ring;
+    u32x4* const s_wr = s_ring + TSLOTS * TM * 4;
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wf = wave >> 2, wt = wave & 3;
-    const int m0 = blockIdx.x * TM, n0 = blockIdx.y * TN;
+    // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so the
+    // feature tiles of one token tile are given ids 8 apart -- same XCD, adjacent in time.
+    const int nft = (p.N + TN - 1) / TN, ntt = (p.M + TM - 1) / TM;
+    const int xcd = blockIdx.x & 7, slot0 = blockIdx.x >> 3;
+    const int ti = (slot0 / nft) * 8 + xcd, fj = slot0 % nft;
+    if (ti >= ntt) return;
+    const int m0 = ti * TM, n0 = fj * TN;
     const long long z = blockIdx.z;
     const u32x4* A0 = reinterpret_cast<const u32x4*>(p.A0) + z * (p.strideA >> 2);
     const u32x4* A1 = p.A1 ? reinterpret_cast<const u32x4*>(p.A1) + z * (p.strideA >> 2) : nullptr;
@@ -60,68 +73,95 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
 
     const int nk = p.K / BK;
     const int wu = __builtin_amdgcn_readfirstlane(wave);
+    const bool tok_wave = wu < 4;  // waves 0-3 stream the token operand, waves 4-7 the weights
+    const int lw = wu & 3;
 
-    // Stage = 128 token rows + 128 feature rows x 128 B, moved HBM/L2 -> LDS by LDS-DMA (global_load_lds,
-    // 1 KiB per wave-instruction, no VGPR round trip and no ds_write traffic).  The DMA writes LDS
-    // linearly (base + lane*16), so the XOR swizzle is applied to the per-lane SOURCE piece instead.
-    // Rows past the edge are clamped to the last valid row (their outputs are never stored).
-    auto issue_stage = [&](int kt, int buf) {
+    // A stage is one 16-deep k-step: 256 token rows x 64 B (from HBM) + 256 feature rows x 64 B (weights,
+    // L2-resident), moved to LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write;
+    // the DMA writes LDS linearly, so the XOR swizzle is applied to the per-lane SOURCE piece; rows
+    // past the edge are clamped, their outputs are never stored).
+    // These GEMMs are HBM-bound (K = 256..512) and vmcnt retires in issue order, so the two operand
+    // streams are issued by DIFFERENT waves with their own ring depth: the token waves keep five stages
+    // (80 KB per CU, 20 MB chip-wide) in flight behind counted vmcnt waits, the weight waves two.
+    auto issue_tok = [&](int kt) {
         const int k0 = kt * BK;
+        u32x4* ring = s_tokr + (kt % TSLOTS) * TM * 4;
         const u32x4* Asrc;
         int lda, kk;
         if (k0 < p.ksplit) { Asrc = A0; lda = p.lda0; kk = k0; } else { Asrc = A1; lda = p.lda1; kk = k0 - p.ksplit; }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int slot = (wu * 4 + j) * 64 + lane, row = slot >> 3, sp = slot & 7;
-            const int sidx = sp ^ ((row >> 1) & 7);
+            const int slot = (lw * 4 + j) * 64 + lane, row = slot >> 2, qp = slot & 3;
+            const int q = qp ^ ((row >> 2) & 3);
             const int gm = min(m0 + row, p.M - 1);
-            __builtin_amdgcn_global_load_lds(Asrc + (((long long)gm * lda + kk) >> 2) + sidx, &s_tok[buf][(wu * 4 + j) * 64], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(Asrc + (((long long)gm * lda + kk) >> 2) + q, ring + (lw * 4 + j) * 64, 16, 0, 0);
         }
+    };
+    auto issue_w = [&](int kt) {
+        const int k0 = kt * BK;
+        u32x4* ring = s_wr + (kt % WSLOTS) * TN * 4;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const int slot = (wu * 4 + j) * 64 + lane, row = slot >> 3, sp = slot & 7;
-            const int sidx = sp ^ ((row >> 1) & 7);
+            const int slot = (lw * 4 + j) * 64 + lane, row = slot >> 2, qp = slot & 3;
+            const int q = qp ^ ((row >> 2) & 3);
             const u32x4* src;
             if (W_ROWMAJOR) {
                 const int gn = min(n0 + row, p.N - 1);
-                src = Wg + (((long long)gn * p.ldw + k0) >> 2) + sidx;
+                src = Wg + (((long long)gn * p.ldw + k0) >> 2) + q;
             } else {
-                src = Wg + ((long long)((k0 >> 4) + (sidx >> 2)) * p.Npad + n0 + row) * 4 + (sidx & 3);
+                src = Wg + ((long long)(k0 >> 4) * p.Npad + n0 + row) * 4 + q;
             }
-            __builtin_amdgcn_global_load_lds(src, &s_w[buf][(wu * 4 + j) * 64], 16, 0, 0);
+            __builtin_amdgcn_global_load_lds(src, ring + (lw * 4 + j) * 64, 16, 0, 0);
         }
     };
 
-    issue_stage(0, 0);
-    __syncthreads();
-
     const int i32 = lane & 31, h = lane >> 5;
-    for (int kt = 0; kt < nk; ++kt) {
-        const int buf = kt & 1;
-        if (kt + 1 < nk) issue_stage(kt + 1, buf ^ 1);
-        const f16x8* st = reinterpret_cast<const f16x8*>(s_tok[buf]);
-        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w[buf]);
-#pragma unroll
-        for (int kc = 0; kc < 2; ++kc) {
-            f16x8 ah[4], al[4], bh[2], bl[2];
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft) {
-                const int row = wf * 128 + ft * 32 + i32;
-                ah[ft] = sw[swz(row, kc * 4 + 2 * h)];
-                al[ft] = sw[swz(row, kc * 4 + 2 * h + 1)];
-            }
-#pragma unroll
-            for (int tt = 0; tt < 2; ++tt) {
-                const int row = wt * 64 + tt * 32 + i32;
-                bh[tt] = st[swz(row, kc * 4 + 2 * h)];
-                bl[tt] = st[swz(row, kc * 4 + 2 * h + 1)];
-            }
-#pragma unroll
-            for (int ft = 0; ft < 4; ++ft)
-#pragma unroll
-                for (int tt = 0; tt < 2; ++tt) mma3(ah[ft], al[ft], bh[tt], bl[tt], acc[ft][tt]);
+    if (tok_wave) {
+#pragma unroll 1
+        for (int s0 = 0; s0 < TSLOTS - 1 && s0 < nk; ++s0) issue_tok(s0);
+    } else {
+#pragma unroll 1
+        for (int s0 = 0; s0 < WSLOTS - 1 && s0 < nk; ++s0) issue_w(s0);
+    }
+    for (int kt = 0; kt < ((p.debug & 2) ? 0 : nk); ++kt) {
+        // each wave waits for ITS loads of stage kt: all but the younger stages of its own stream
+        if (tok_wave) {
+            const int ahead = min(TSLOTS - 2, nk - 1 - kt);
+            if (ahead == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else {
+            const int ahead = min(WSLOTS - 2, nk - 1 - kt);
+            if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
-        __syncthreads();  // drains this stage's DMA (vmcnt(0)) and fences the buffer swap
+        __builtin_amdgcn_s_barrier();  // stage kt is complete in LDS; everyone is done with stage kt-1
+        if (tok_wave) {
+            if (kt + TSLOTS - 1 < nk) issue_tok(kt + TSLOTS - 1);  // into the slot stage kt-1 just vacated
+        } else {
+            if (kt + WSLOTS - 1 < nk) issue_w(kt + WSLOTS - 1);
+        }
+        const f16x8* st = reinterpret_cast<const f16x8*>(s_tokr + (kt % TSLOTS) * TM * 4);
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_wr + (kt % WSLOTS) * TN * 4);
+        f16x8 ah[4], al[4], bh[2], bl[2];
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft) {
+            const int row = wf * 128 + ft * 32 + i32;
+            ah[ft] = sw[swz(row, 2 * h)];
+            al[ft] = sw[swz(row, 2 * h + 1)];
+        }
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int row = wt * 64 + tt * 32 + i32;
+            bh[tt] = st[swz(row, 2 * h)];
+            bl[tt] = st[swz(row, 2 * h + 1)];
+        }
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) mma3(ah[ft], al[ft], bh[tt], bl[tt], acc[ft][tt]);
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
@@ -188,7 +228,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
 #pragma unroll
                     for (int j = 0; j < 16; ++j) w[j] *= p.scale;
                 }
-                if (tok_ok) {
+                if (tok_ok && !(p.debug & 1)) {
                     if (p.residual) {
                         const float* rs = p.residual + tokc * p.ldr + fb;
 #pragma unroll
@@ -239,8 +279,12 @@ __global__ __launch_bounds__(256) void to_sh8_kernel(const float* __restrict__ i
 
 }  // namespace
 
-void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s) {
-    dim3 grid((a.M + TM - 1) / TM, (a.N + TN - 1) / TN, a.batch);
+void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
+    static const int dbg = getenv("MG_GEMM_DEBUG") ? atoi(getenv("MG_GEMM_DEBUG")) : 0;  // timing experiments only
+    GemmF16Args a = a0;
+    a.debug = dbg;
+    const int ntt = (a.M + TM - 1) / TM, nft = (a.N + TN - 1) / TN;
+    dim3 grid(((ntt + 7) / 8) * 8 * nft, 1, a.batch);
     if (a.w_rowmajor)
         hipLaunchKernelGGL(gemm_f16x3_kernel<true>, grid, dim3(GT), 0, s, a);
     else

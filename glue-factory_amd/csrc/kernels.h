@@ -108,6 +108,7 @@ struct GemmF16Args {
     int ldr = 0;
     int batch = 1;
     long long strideA = 0, strideW = 0, strideC = 0, strideCs = 0;  // elements
+    int debug = 0;  // timing experiments: 1 = skip the stores, 2 = skip the main loop
 };
 void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s);
 void launch_to_sh8(const float* in, void* out, long long elems, hipStream_t s);
