@@ -41,13 +41,14 @@ __device__ __attribute__((noinline)) void epilogue_ragged(const GemmF16Args& p, 
     }
 }
 
-template <bool W_ROWMAJOR>
+template <bool W_ROWMAJOR, bool RAGGED>
 __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
     // ONE LDS array (a second __shared__ object next to LDS-DMA staging makes hipcc drain vmcnt before
     // every fragment read): [token ring: 6 x 256 rows x 64 B][weight ring: 3 x 256 rows x 64 B] = 144 KB
-    __shared__ u32x4 s_ring[(TSLOTS * TM + WSLOTS * TN) * 4];
+    __shared__ u32x4 s_ring[(TSLOTS * TM + WSLOTS * TN) * 4 + 3 * TN / 4];  // + bias | post_scale | post_shift of this feature tile
     u32x4* const s_tokr = s_ring;
     u32x4* const s_wr = s_ring + TSLOTS * TM * 4;
+    float* const s_par = reinterpret_cast<float*>(s_ring + (TSLOTS * TM + WSLOTS * TN) * 4);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wf = wave >> 2, wt = wave & 3;
@@ -123,6 +124,14 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
 #pragma unroll 1
         for (int s0 = 0; s0 < WSLOTS - 1 && s0 < nk; ++s0) issue_w(s0);
     }
+    // per-feature epilogue parameters -> LDS (one global round trip per workgroup, under the DMA prologue)
+    for (int i = t; i < TN; i += GT) {
+        const int f = n0 + i;
+        const bool ok = f < p.N;
+        s_par[i] = (p.bias && ok) ? p.bias[f] : 0.f;
+        s_par[TN + i] = (p.post_scale && ok) ? p.post_scale[f] : 1.f;
+        s_par[2 * TN + i] = (p.post_shift && ok) ? p.post_shift[f] : 0.f;
+    }
     for (int kt = 0; kt < ((p.debug & 2) ? 0 : nk); ++kt) {
         // each wave waits for ITS loads of stage kt: all but the younger stages of its own stream
         if (tok_wave) {
@@ -169,6 +178,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
     // path is straight-line code with 16-byte loads and stores; only a tile that straddles N (the
     // 65-channel detector head) takes the element-wise path.
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> inline-asm permlane reads
+    __builtin_amdgcn_s_barrier();                         // s_par visible (also when the k-loop was empty)
     float* C = p.C ? p.C + z * p.strideC : nullptr;
     const int wfu = wu >> 2;
 #pragma unroll
@@ -191,10 +201,11 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
                 w[e] = a0; w[4 + e] = b0; w[8 + e] = a1; w[12 + e] = b1;
             }
             if (full) {
-                if (p.bias) {
+                {
+                    const float* bp = s_par + (fb - n0);
 #pragma unroll
                     for (int j = 0; j < 16; j += 4) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(p.bias + fb + j);
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + j);
                         w[j] += bv.x; w[j + 1] += bv.y; w[j + 2] += bv.z; w[j + 3] += bv.w;
                     }
                 }
@@ -218,8 +229,8 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
                 if (p.post_scale) {
 #pragma unroll
                     for (int j = 0; j < 16; j += 4) {
-                        const f32x4 a = *reinterpret_cast<const f32x4*>(p.post_scale + fb + j);
-                        const f32x4 c = *reinterpret_cast<const f32x4*>(p.post_shift + fb + j);
+                        const f32x4 a = *reinterpret_cast<const f32x4*>(s_par + TN + (fb - n0) + j);
+                        const f32x4 c = *reinterpret_cast<const f32x4*>(s_par + 2 * TN + (fb - n0) + j);
                         w[j] = __fadd_rn(__fmul_rn(w[j], a.x), c.x); w[j + 1] = __fadd_rn(__fmul_rn(w[j + 1], a.y), c.y);
                         w[j + 2] = __fadd_rn(__fmul_rn(w[j + 2], a.z), c.z); w[j + 3] = __fadd_rn(__fmul_rn(w[j + 3], a.w), c.w);
                     }
@@ -258,7 +269,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
                     }
                 }
             } else {
-                epilogue_ragged(p, C, w, fb, tokc, tok_ok);
+                if (RAGGED) epilogue_ragged(p, C, w, fb, tokc, tok_ok);  // only instantiated when N % 32 != 0 (keeps scratch out of the hot kernel)
             }
         }
     }
@@ -285,10 +296,14 @@ void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
     a.debug = dbg;
     const int ntt = (a.M + TM - 1) / TM, nft = (a.N + TN - 1) / TN;
     dim3 grid(((ntt + 7) / 8) * 8 * nft, 1, a.batch);
-    if (a.w_rowmajor)
-        hipLaunchKernelGGL(gemm_f16x3_kernel<true>, grid, dim3(GT), 0, s, a);
-    else
-        hipLaunchKernelGGL(gemm_f16x3_kernel<false>, grid, dim3(GT), 0, s, a);
+    const bool ragged = (a.N & 31) != 0;
+    if (a.w_rowmajor) {
+        if (ragged) hipLaunchKernelGGL((gemm_f16x3_kernel<true, true>), grid, dim3(GT), 0, s, a);
+        else hipLaunchKernelGGL((gemm_f16x3_kernel<true, false>), grid, dim3(GT), 0, s, a);
+    } else {
+        if (ragged) hipLaunchKernelGGL((gemm_f16x3_kernel<false, true>), grid, dim3(GT), 0, s, a);
+        else hipLaunchKernelGGL((gemm_f16x3_kernel<false, false>), grid, dim3(GT), 0, s, a);
+    }
 }
 
 void launch_to_sh8(const float* in, void* out, long long elems, hipStream_t s) {
