@@ -11,7 +11,8 @@ from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int6
 import torch
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(os.path.dirname(_PKG), "lib", "libmatchglue.so")
+# MG_LIB_PATH lets a benchmark A/B two builds of the library in one process tree (same device, same clocks)
+LIB_PATH = os.environ.get("MG_LIB_PATH") or os.path.join(os.path.dirname(_PKG), "lib", "libmatchglue.so")
 
 MG_SP_MAGICLEAP, MG_SP_OPEN = 0, 1
 MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN = 0, 1, 2
