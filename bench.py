@@ -190,7 +190,7 @@ def main():
         # HBM bytes per launch of the dominant kernel: from the committed rocprofv3 PMC passes of this same
         # command (profiles/summarize_pmc.py; FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), not live
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", f"r01_b_{args.precision}_hbm_traffic.json")
+        tpath = os.path.join(ROOT, "profiles", f"r01_c_{args.precision}_hbm_traffic.json")
         if os.path.exists(tpath) and B == PAIRS:
             tj = json.load(open(tpath))
             if dom in tj:

@@ -45,7 +45,7 @@ struct DevBuf {
         if (need <= bytes) return 0;
         if (p) {
             if (hipDeviceSynchronize() != hipSuccess) return -1;
-            hipFree(p);
+            (void)hipFree(p);
             p = nullptr;
             bytes = 0;
         }
@@ -59,7 +59,7 @@ struct DevBuf {
     }
     float* f() const { return static_cast<float*>(p); }
     void release() {
-        if (p) hipFree(p);
+        if (p) (void)hipFree(p);
         p = nullptr;
         bytes = 0;
     }
@@ -127,7 +127,7 @@ struct mg_context {
     hipEvent_t next_event() {
         if (event_used == event_pool.size()) {
             hipEvent_t e;
-            hipEventCreate(&e);
+            (void)hipEventCreate(&e);
             event_pool.push_back(e);
         }
         return event_pool[event_used++];
@@ -147,12 +147,12 @@ struct ProfScope {
         e.name = name;
         e.a = h->next_event();
         e.b = h->next_event();
-        hipEventRecord(e.a, s);
+        (void)hipEventRecord(e.a, s);
         idx = h->prof.size();
         h->prof.push_back(e);
     }
     ~ProfScope() {
-        if (on) hipEventRecord(h->prof[idx].b, s);
+        if (on) (void)hipEventRecord(h->prof[idx].b, s);
     }
 };
 
@@ -504,12 +504,12 @@ int mg_create(int device, mg_handle* out) {
 
 int mg_destroy(mg_handle h) {
     if (!h) return 0;
-    hipSetDevice(h->device);
-    hipDeviceSynchronize();
-    for (void* p : h->owned) hipFree(p);
+    (void)hipSetDevice(h->device);
+    (void)hipDeviceSynchronize();
+    for (void* p : h->owned) (void)hipFree(p);
     for (auto& kv : h->ws) kv.second.release();
     for (auto& kv : h->taps) kv.second.release();
-    for (auto e : h->event_pool) hipEventDestroy(e);
+    for (auto e : h->event_pool) (void)hipEventDestroy(e);
     delete h;
     return 0;
 }

@@ -15,8 +15,8 @@ import sys
 SHORT = {
     "conv1ab_f16x3_kernel": "sp.conv1ab",
     "conv3x3_f16x3_kernel": "sp.conv3x3",
-    "gemm_f16x3_kernel<false>": "gemm (tiled weights)",
-    "gemm_f16x3_kernel<true>": "lg.gemm.sim",
+    "gemm_f16x3_kernel<false": "gemm (tiled weights)",
+    "gemm_f16x3_kernel<true": "lg.gemm.sim",
     "attention_f16x3_kernel": "lg.attn",
     "nms_kernel": "sp.nms",
     "ln_gelu_kernel": "lg.ln_gelu",
