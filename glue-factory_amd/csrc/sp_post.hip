@@ -74,6 +74,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // tile per block with a 5r halo (the dependency radius of the three keep/suppress rounds).
 // max_pool2d pads with -inf, so everything outside the image is -inf / "not kept".
 constexpr int NMS_TILE = 32;
+constexpr int NMS_THREADS = 1024;  // 2 blocks/CU x 8 waves: the kernel is LDS-latency-bound, occupancy hides it
 constexpr int COUNT_STRIDE = 32;  // ints between per-image candidate counters (one 128-B line each)
 
 // Separable (2R+1)^2 max-pool over a TxT LDS tile (row stride TP).  Each thread produces 4 adjacent
@@ -82,7 +83,7 @@ constexpr int COUNT_STRIDE = 32;  // ints between per-image candidate counters (
 template <int R, int T, int TP>
 __device__ __forceinline__ void pool_pass(const float* src, float* tmp, float* dst) {
     constexpr int G = (T + 3) / 4;  // groups of 4 along the pooled axis
-    for (int i = threadIdx.x; i < T * G; i += 256) {
+    for (int i = threadIdx.x; i < T * G; i += NMS_THREADS) {
         const int y = i / G, x0 = (i - y * G) * 4;
         float w[4 + 2 * R];
 #pragma unroll
@@ -96,7 +97,7 @@ __device__ __forceinline__ void pool_pass(const float* src, float* tmp, float* d
         }
     }
     __syncthreads();
-    for (int i = threadIdx.x; i < T * G; i += 256) {
+    for (int i = threadIdx.x; i < T * G; i += NMS_THREADS) {
         const int g = i / T, x = i - g * T, y0 = g * 4;
         float w[4 + 2 * R];
 #pragma unroll
@@ -113,7 +114,7 @@ __device__ __forceinline__ void pool_pass(const float* src, float* tmp, float* d
 }
 
 template <int R>
-__global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
+__global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const DetectArgs p) {
     constexpr int halo = 5 * R, T = NMS_TILE + 2 * halo, TP = (T + 3) / 4 * 4 + 1, n = T * T;
     __shared__ float s_s[T * TP];
     __shared__ float s_a[T * TP];
@@ -126,7 +127,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
     const float* heat = p.heat + (long long)b * p.Hs * p.Ws;
     const float NEG = -__builtin_inff();
 
-    for (int i = threadIdx.x; i < n; i += 256) {
+    for (int i = threadIdx.x; i < n; i += NMS_THREADS) {
         const int y = i / T, x = i - y * T;
         const int gy = y0 + y, gx = x0 + x;
         s_s[y * TP + x] = (gy >= 0 && gy < p.Hs && gx >= 0 && gx < p.Ws) ? heat[(long long)gy * p.Ws + gx] : NEG;
@@ -134,19 +135,19 @@ __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
     __syncthreads();
     if (R > 0) {
         pool_pass<R, T, TP>(s_s, s_t, s_a);
-        for (int i = threadIdx.x; i < n; i += 256) {
+        for (int i = threadIdx.x; i < n; i += NMS_THREADS) {
             const int y = i / T, o = y * TP + (i - y * T);
             s_keep[o] = (s_s[o] != NEG) && (s_s[o] == s_a[o]);
         }
         __syncthreads();
         for (int it = 0; it < 2; ++it) {
-            for (int i = threadIdx.x; i < n; i += 256) {
+            for (int i = threadIdx.x; i < n; i += NMS_THREADS) {
                 const int y = i / T, o = y * TP + (i - y * T);
                 s_a[o] = s_keep[o] ? 1.f : 0.f;
             }
             __syncthreads();
             pool_pass<R, T, TP>(s_a, s_t, s_a);
-            for (int i = threadIdx.x; i < n; i += 256) {
+            for (int i = threadIdx.x; i < n; i += NMS_THREADS) {
                 const int y = i / T, o = y * TP + (i - y * T);
                 const unsigned char sp = s_a[o] > 0.f;
                 s_supp[o] = sp;
@@ -154,7 +155,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
             }
             __syncthreads();
             pool_pass<R, T, TP>(s_a, s_t, s_a);
-            for (int i = threadIdx.x; i < n; i += 256) {
+            for (int i = threadIdx.x; i < n; i += NMS_THREADS) {
                 const int y = i / T, o = y * TP + (i - y * T);
                 if (s_s[o] == NEG) continue;
                 const float rest = s_supp[o] ? 0.f : s_s[o];
@@ -163,7 +164,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
             __syncthreads();
         }
     } else {
-        for (int i = threadIdx.x; i < T * TP; i += 256) s_keep[i] = 1;  // radius 0: every pixel is its own maximum
+        for (int i = threadIdx.x; i < T * TP; i += NMS_THREADS) s_keep[i] = 1;  // radius 0: every pixel is its own maximum
         __syncthreads();
     }
 
@@ -178,7 +179,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
         wlim = (int)p.image_size[2 * b];
         hlim = (int)p.image_size[2 * b + 1];
     }
-    for (int i = threadIdx.x; i < NMS_TILE * NMS_TILE; i += 256) {
+    for (int i = threadIdx.x; i < NMS_TILE * NMS_TILE; i += NMS_THREADS) {
         const int ty = i >> 5, tx = i & 31;
         const int gy = blockIdx.y * NMS_TILE + ty, gx = blockIdx.x * NMS_TILE + tx;
         if (gy >= p.Hs || gx >= p.Ws) continue;
@@ -200,7 +201,7 @@ __global__ __launch_bounds__(256) void nms_kernel(const DetectArgs p) {
     if (threadIdx.x == 0) s_base = atomicAdd(&p.counts[b * COUNT_STRIDE], cnt);
     __syncthreads();
     unsigned long long* dst = p.cand + (long long)b * p.Hs * p.Ws + s_base;
-    for (int i = threadIdx.x; i < cnt; i += 256) dst[i] = s_cand[i];
+    for (int i = threadIdx.x; i < cnt; i += NMS_THREADS) dst[i] = s_cand[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -391,11 +392,11 @@ void launch_detect(const DetectArgs& a, hipStream_t s) {
     (void)hipMemsetAsync(a.counts, 0, sizeof(int) * a.B * COUNT_STRIDE, s);
     dim3 grid((a.Ws + NMS_TILE - 1) / NMS_TILE, (a.Hs + NMS_TILE - 1) / NMS_TILE, a.B);
     switch (a.radius) {
-        case 0: hipLaunchKernelGGL(nms_kernel<0>, grid, dim3(256), 0, s, a); break;
-        case 1: hipLaunchKernelGGL(nms_kernel<1>, grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(nms_kernel<2>, grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(nms_kernel<3>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(nms_kernel<4>, grid, dim3(256), 0, s, a); break;
+        case 0: hipLaunchKernelGGL(nms_kernel<0>, grid, dim3(NMS_THREADS), 0, s, a); break;
+        case 1: hipLaunchKernelGGL(nms_kernel<1>, grid, dim3(NMS_THREADS), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(nms_kernel<2>, grid, dim3(NMS_THREADS), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(nms_kernel<3>, grid, dim3(NMS_THREADS), 0, s, a); break;
+        default: hipLaunchKernelGGL(nms_kernel<4>, grid, dim3(NMS_THREADS), 0, s, a); break;
     }
     hipLaunchKernelGGL(select_kernel, dim3(a.B), dim3(SEL_THREADS), 0, s, a);
 }
