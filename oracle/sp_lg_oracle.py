@@ -508,3 +508,133 @@ def make_lg_weights(seed=0, n_layers=9, dim=256, structured=True, final_gain=4.0
         if i < n_layers - 1:
             W[f"token_confidence.{i}.token.0.weight"], W[f"token_confidence.{i}.token.0.bias"] = lin(1, dim)
     return W
+
+
+# --------------------------------------------------------------------------
+# SuperGlue (gluefactory_nonfree/superglue.py:208-307)
+# --------------------------------------------------------------------------
+def sg_normalize_keypoints(kpts, size):
+    """superglue.py:74-86 -- centre on the image, divide by 0.7 * longer side."""
+    size = torch.as_tensor(size).to(kpts)
+    if size.dim() == 1:
+        size = size[None]
+    shift = size / 2
+    scale = size.max(1).values * 0.7
+    return (kpts - shift[:, None]) / scale[:, None, None]
+
+
+def _sg_mlp(x, W, prefix, n_layers):
+    """superglue.py:63-72 -- Conv1d(k=1) [+ BatchNorm1d + ReLU] chain on (B,C,N); last layer is plain."""
+    idx = 0
+    for i in range(n_layers):
+        x = F.conv1d(x, W[f"{prefix}.{idx}.weight"], W[f"{prefix}.{idx}.bias"])
+        idx += 1
+        if i < n_layers - 1:
+            x = F.batch_norm(x, W[f"{prefix}.{idx}.running_mean"], W[f"{prefix}.{idx}.running_var"],
+                             W[f"{prefix}.{idx}.weight"], W[f"{prefix}.{idx}.bias"], training=False, eps=1e-5)
+            x = F.relu(x)
+            idx += 2
+    return x
+
+
+def _sg_propagate(x, src, W, p, heads=4):
+    """superglue.py:105-141 -- multi-head attention (channel = dim*heads + head) + merge + MLP([512,512,256])."""
+    b = x.shape[0]
+    dim = x.shape[1] // heads
+    q = F.conv1d(x, W[p + ".attn.proj.0.weight"], W[p + ".attn.proj.0.bias"]).view(b, dim, heads, -1)
+    k = F.conv1d(src, W[p + ".attn.proj.1.weight"], W[p + ".attn.proj.1.bias"]).view(b, dim, heads, -1)
+    v = F.conv1d(src, W[p + ".attn.proj.2.weight"], W[p + ".attn.proj.2.bias"]).view(b, dim, heads, -1)
+    scores = torch.einsum("bdhn,bdhm->bhnm", q, k) / dim ** 0.5
+    prob = torch.softmax(scores, dim=-1)
+    msg = torch.einsum("bhnm,bdhm->bdhn", prob, v).contiguous().view(b, dim * heads, -1)
+    msg = F.conv1d(msg, W[p + ".attn.merge.weight"], W[p + ".attn.merge.bias"])
+    return _sg_mlp(torch.cat([x, msg], 1), W, p + ".mlp", 2)
+
+
+def log_optimal_transport(scores, alpha, iters):
+    """superglue.py:173-201 -- log-domain Sinkhorn with a dustbin row/column."""
+    b, m, n = scores.shape
+    one = scores.new_tensor(1)
+    ms, ns = (m * one), (n * one)
+    bins0 = alpha.expand(b, m, 1)
+    bins1 = alpha.expand(b, 1, n)
+    al = alpha.expand(b, 1, 1)
+    Z = torch.cat([torch.cat([scores, bins0], -1), torch.cat([bins1, al], -1)], 1)
+    norm = -(ms + ns).log()
+    log_mu = torch.cat([norm.expand(m), ns.log()[None] + norm])[None].expand(b, -1)
+    log_nu = torch.cat([norm.expand(n), ms.log()[None] + norm])[None].expand(b, -1)
+    u, v = torch.zeros_like(log_mu), torch.zeros_like(log_nu)
+    for _ in range(iters):
+        u = log_mu - torch.logsumexp(Z + v.unsqueeze(1), dim=2)
+        v = log_nu - torch.logsumexp(Z + u.unsqueeze(2), dim=1)
+    return Z + u.unsqueeze(2) + v.unsqueeze(1) - norm
+
+
+SG_DEFAULTS = dict(n_layers=18, num_sinkhorn_iterations=50, filter_threshold=0.2)
+
+
+def superglue_forward(data, W, **conf):
+    """superglue.py:253-307 (use_scores=True, keypoint_encoder [32,64,128,256], descriptor_dim 256)."""
+    cfg = {**SG_DEFAULTS, **conf}
+    d0 = data["descriptors0"].transpose(-1, -2)
+    d1 = data["descriptors1"].transpose(-1, -2)
+    k0 = sg_normalize_keypoints(data["keypoints0"], data["view0"]["image_size"])
+    k1 = sg_normalize_keypoints(data["keypoints1"], data["view1"]["image_size"])
+    enc0 = _sg_mlp(torch.cat([k0.transpose(1, 2), data["keypoint_scores0"].unsqueeze(1)], 1), W, "kenc.encoder", 5)
+    enc1 = _sg_mlp(torch.cat([k1.transpose(1, 2), data["keypoint_scores1"].unsqueeze(1)], 1), W, "kenc.encoder", 5)
+    d0, d1 = d0 + enc0, d1 + enc1
+    taps = {"kenc": (d0.clone(), d1.clone())}
+    for i in range(cfg["n_layers"]):
+        p = f"gnn.layers.{i}"
+        if i % 2 == 0:
+            e0, e1 = _sg_propagate(d0, d0, W, p), _sg_propagate(d1, d1, W, p)
+        else:
+            e0, e1 = _sg_propagate(d0, d1, W, p), _sg_propagate(d1, d0, W, p)
+        d0, d1 = d0 + e0, d1 + e1
+        if i in (0, 1, cfg["n_layers"] - 1):
+            taps[i] = (d0.clone(), d1.clone())
+    m0 = F.conv1d(d0, W["final_proj.weight"], W["final_proj.bias"])
+    m1 = F.conv1d(d1, W["final_proj.weight"], W["final_proj.bias"])
+    cost = torch.einsum("bdn,bdm->bnm", m0, m1) / 256 ** 0.5
+    S = log_optimal_transport(cost, W["bin_score"], cfg["num_sinkhorn_iterations"])
+    mt0, mt1, ms0, ms1, am0, am1 = filter_matches(S, cfg["filter_threshold"])
+    return {"sinkhorn_cost": cost, "log_assignment": S, "matches0": mt0, "matches1": mt1,
+            "matching_scores0": ms0, "matching_scores1": ms1, "_taps": taps}
+
+
+def make_sg_weights(seed=0, n_layers=18, final_gain=6.0, bin_score=1.0):
+    """Seeded SuperGlue weights under the reference's state_dict key names (superglue.py:208-250)."""
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+
+    def conv(name, co, ci, gain=1.0, zero_bias=False):
+        W[name + ".weight"] = torch.randn(co, ci, 1, generator=g) * gain / math.sqrt(ci)
+        W[name + ".bias"] = torch.zeros(co) if zero_bias else torch.randn(co, generator=g) * 0.05
+
+    def bn(name, c):
+        W[name + ".weight"] = 0.75 + 0.5 * torch.rand(c, generator=g)
+        W[name + ".bias"] = 0.2 * (torch.rand(c, generator=g) - 0.5)
+        W[name + ".running_mean"] = 0.2 * (torch.rand(c, generator=g) - 0.5)
+        W[name + ".running_var"] = 0.5 + torch.rand(c, generator=g)
+        W[name + ".num_batches_tracked"] = torch.tensor(0)
+
+    chans = [3, 32, 64, 128, 256, 256]
+    idx = 0
+    for i in range(5):
+        conv(f"kenc.encoder.{idx}", chans[i + 1], chans[i], gain=0.3 if i == 4 else 1.4, zero_bias=(i == 4))
+        idx += 1
+        if i < 4:
+            bn(f"kenc.encoder.{idx}", chans[i + 1])
+            idx += 2
+    for l in range(n_layers):
+        p = f"gnn.layers.{l}"
+        conv(p + ".attn.merge", 256, 256, gain=0.5)
+        for j in range(3):
+            conv(p + f".attn.proj.{j}", 256, 256, gain=1.0)
+        conv(p + ".mlp.0", 512, 512, gain=1.4)
+        bn(p + ".mlp.1", 512)
+        conv(p + ".mlp.3", 256, 512, gain=0.3, zero_bias=True)
+    W["final_proj.weight"] = (torch.eye(256) * final_gain)[:, :, None].contiguous()
+    W["final_proj.bias"] = torch.zeros(256)
+    W["bin_score"] = torch.tensor(float(bin_score))
+    return W

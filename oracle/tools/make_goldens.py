@@ -228,6 +228,43 @@ def gold_lightglue():
     save("lightglue", **arrs)
 
 
+# ---------------------------------------------------------------- (4b) SuperGlue
+def gold_superglue():
+    import gluefactory_nonfree.superglue as ref_sg
+
+    arrs = {}
+    for tag, B, M, N, seed in (("a", 2, 40, 33, 3), ("b", 1, 64, 64, 4), ("c", 2, 17, 100, 5)):
+        g = torch.Generator().manual_seed(200 + seed)
+        W = O.make_sg_weights(seed)
+        size0 = torch.tensor([[640.0, 480.0]] * B)
+        size1 = torch.tensor([[600.0, 480.0]] * B)
+        K = max(M, N)
+        kk = torch.rand(B, K, 2, generator=g) * size1[:, None] * 0.98 + 0.5
+        dd = torch.nn.functional.normalize(torch.randn(B, K, 256, generator=g), dim=-1)
+        k0, d0 = kk[:, :M].contiguous(), dd[:, :M].contiguous()
+        perm = torch.stack([torch.randperm(K, generator=g)[:N] for _ in range(B)])
+        k1 = (torch.gather(kk, 1, perm[..., None].expand(-1, -1, 2)) * 0.9 + 3.0 * torch.randn(B, N, 2, generator=g)).clamp(1.0, 479.0)
+        d1 = torch.nn.functional.normalize(torch.gather(dd, 1, perm[..., None].expand(-1, -1, 256)) + 0.05 * torch.randn(B, N, 256, generator=g), dim=-1)
+        s0, s1 = torch.rand(B, M, generator=g), torch.rand(B, N, generator=g)
+        data = {"keypoints0": k0, "keypoints1": k1, "descriptors0": d0, "descriptors1": d1, "keypoint_scores0": s0, "keypoint_scores1": s1,
+                "view0": {"image_size": size0, "image": torch.zeros(B, 1, 480, 640)}, "view1": {"image_size": size1, "image": torch.zeros(B, 1, 480, 600)}}
+        for k in ("keypoints0", "keypoints1", "descriptors0", "descriptors1", "keypoint_scores0", "keypoint_scores1"):
+            arrs[f"{tag}.{k}"] = data[k]
+        arrs[f"{tag}.size0"], arrs[f"{tag}.size1"] = size0, size1
+        for th in (0.0, 0.2):
+            m = ref_sg.SuperGlue({"weights": None, "filter_threshold": th}).eval()
+            missing, unexpected = m.load_state_dict(W, strict=False)
+            assert not missing and not unexpected
+            p = m(data)
+            for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+                arrs[f"{tag}.th{th}.{k}"] = p[k]
+            if th == 0.0:
+                arrs[f"{tag}.log_assignment"] = p["log_assignment"]
+                arrs[f"{tag}.sinkhorn_cost"] = p["sinkhorn_cost"]
+        print("superglue", tag, "matches", int((p["matches0"] > -1).sum()), "of", B * M)
+    save("superglue", **arrs)
+
+
 # ---------------------------------------------------------------- (5) two-view pipeline on the boat pair
 def gold_two_view(boat):
     g0 = np.round(boat[0].astype(np.float32) @ np.array([0.299, 0.587, 0.114], np.float32)).astype(np.uint8)
@@ -282,4 +319,5 @@ if __name__ == "__main__":
     gold_nms_topk()
     gold_superpoint(boat)
     gold_lightglue()
+    gold_superglue()
     gold_two_view(boat)

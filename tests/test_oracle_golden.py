@@ -138,3 +138,27 @@ def test_two_view_boat_matches_reference(golden):
         for k in ("keypoints0", "keypoints1", "matches0", "matches1"):
             assert torch.equal(p[k], g[f"{variant}.shift.{k}"]), (variant, k)
         assert int((p["matches0"] > -1).sum()) > 400
+
+
+def _sg_data(g, tag):
+    return {
+        "keypoints0": g[tag + ".keypoints0"], "keypoints1": g[tag + ".keypoints1"],
+        "descriptors0": g[tag + ".descriptors0"], "descriptors1": g[tag + ".descriptors1"],
+        "keypoint_scores0": g[tag + ".keypoint_scores0"], "keypoint_scores1": g[tag + ".keypoint_scores1"],
+        "view0": {"image_size": g[tag + ".size0"]}, "view1": {"image_size": g[tag + ".size1"]},
+    }
+
+
+def test_superglue_matches_reference(golden):
+    """gluefactory_nonfree/superglue.py run by oracle/tools/make_goldens.py."""
+    g = golden("superglue")
+    for tag, seed in (("a", 3), ("b", 4), ("c", 5)):
+        W = O.make_sg_weights(seed)
+        for th in (0.0, 0.2):
+            p = O.superglue_forward(_sg_data(g, tag), W, filter_threshold=th)
+            for k in ("matches0", "matches1"):
+                assert torch.equal(p[k], g[f"{tag}.th{th}.{k}"]), (tag, th, k)
+            for k in ("matching_scores0", "matching_scores1"):
+                torch.testing.assert_close(p[k], g[f"{tag}.th{th}.{k}"], rtol=0, atol=1e-5)
+        torch.testing.assert_close(p["sinkhorn_cost"], g[tag + ".sinkhorn_cost"], rtol=1e-5, atol=1e-4)
+        torch.testing.assert_close(p["log_assignment"], g[tag + ".log_assignment"], rtol=1e-5, atol=1e-4)
