@@ -93,7 +93,7 @@ struct ProfEntry {
 struct mg_context {
     int device = 0;
     int precision = MG_PREC_F16X3;
-    std::map<std::string, HostTensor> raw[2];
+    std::map<std::string, HostTensor> raw[3];
     std::vector<void*> owned;  // device allocations of prepared weights
 
     // SuperPoint
@@ -108,6 +108,13 @@ struct mg_context {
     float* match_w = nullptr;
     float match_b = 0.f;
     float* Wr = nullptr;
+    // SuperGlue
+    int sg_layers = -1;
+    LinLayer sg_kenc[5];
+    struct SgLayer { LinLayer proj, mlp0f, mlp3; };
+    std::vector<SgLayer> sg_gnn;
+    LinLayer sg_final;
+    float sg_bin = 1.f;
 
     // workspace
     std::map<std::string, DevBuf> ws;
@@ -412,6 +419,132 @@ int prepare_lg(mg_context* h, int n_layers) {
     return 0;
 }
 
+// ---- SuperGlue weights (gluefactory_nonfree/superglue.py:63-72,118-141,208-250) --------------------
+// Conv1d(k=1) == Linear.  BatchNorm1d (eval) after a conv is folded into that conv in fp64; the
+// attention heads use channel = dim*4 + head (:123-128), re-ordered here to [head][dim]; `merge` is
+// folded into mlp.0 exactly like LightGlue's out-projection (the message only feeds the MLP, :139-141).
+struct BnFold { std::vector<double> s, t; };
+
+int sg_bn(mg_context* h, const std::string& prefix, int C, BnFold* out) {
+    const HostTensor *g, *b, *m, *v;
+    if (int rc = need(h, 2, prefix + ".weight", {C}, &g)) return rc;
+    if (int rc = need(h, 2, prefix + ".bias", {C}, &b)) return rc;
+    if (int rc = need(h, 2, prefix + ".running_mean", {C}, &m)) return rc;
+    if (int rc = need(h, 2, prefix + ".running_var", {C}, &v)) return rc;
+    out->s.resize(C);
+    out->t.resize(C);
+    for (int c = 0; c < C; ++c) {
+        const double s = (double)g->data[c] / std::sqrt((double)v->data[c] + 1e-5);
+        out->s[c] = s;
+        out->t[c] = (double)b->data[c] - (double)m->data[c] * s;
+    }
+    return 0;
+}
+
+int sg_linear(mg_context* h, const std::vector<std::vector<double>>& W, const std::vector<double>& bias, int Kpad, LinLayer* L) {
+    const int N = (int)W.size();
+    std::vector<float> flat((size_t)N * Kpad, 0.f), bf(N);
+    std::vector<const float*> rows(N);
+    for (int n = 0; n < N; ++n) {
+        for (size_t k = 0; k < W[n].size(); ++k) flat[(size_t)n * Kpad + k] = (float)W[n][k];
+        rows[n] = flat.data() + (size_t)n * Kpad;
+        bf[n] = (float)bias[n];
+    }
+    return prep_linear_rows(h, rows, bf, Kpad, L);
+}
+
+int prepare_sg(mg_context* h, int n_layers) {
+    if (h->sg_layers == n_layers) return 0;
+    const int chans[6] = {3, 32, 64, 128, 256, 256};
+    const int conv_idx[5] = {0, 3, 6, 9, 12};
+    for (int i = 0; i < 5; ++i) {
+        const int ci = chans[i], co = chans[i + 1];
+        const std::string cn = "kenc.encoder." + std::to_string(conv_idx[i]);
+        const HostTensor *w, *b;
+        if (int rc = need(h, 2, cn + ".weight", {co, ci, 1}, &w)) return rc;
+        if (int rc = need(h, 2, cn + ".bias", {co}, &b)) return rc;
+        BnFold bn;
+        const bool has_bn = i < 4;
+        if (has_bn)
+            if (int rc = sg_bn(h, "kenc.encoder." + std::to_string(conv_idx[i] + 1), co, &bn)) return rc;
+        std::vector<std::vector<double>> W(co, std::vector<double>(ci));
+        std::vector<double> bias(co);
+        for (int n = 0; n < co; ++n) {
+            const double s = has_bn ? bn.s[n] : 1.0, t = has_bn ? bn.t[n] : 0.0;
+            for (int k = 0; k < ci; ++k) W[n][k] = (double)w->data[(size_t)n * ci + k] * s;
+            bias[n] = (double)b->data[n] * s + t;
+        }
+        h->sg_kenc[i] = LinLayer();
+        if (int rc = sg_linear(h, W, bias, ci < 32 ? 32 : ci, &h->sg_kenc[i])) return rc;
+    }
+    h->sg_gnn.assign(n_layers, mg_context::SgLayer());
+    for (int l = 0; l < n_layers; ++l) {
+        const std::string p = "gnn.layers." + std::to_string(l);
+        // [q ; k ; v] with rows re-ordered to [head][dim]
+        std::vector<std::vector<double>> W(768, std::vector<double>(256));
+        std::vector<double> bias(768);
+        for (int which = 0; which < 3; ++which) {
+            const HostTensor *w, *b;
+            if (int rc = need(h, 2, p + ".attn.proj." + std::to_string(which) + ".weight", {256, 256, 1}, &w)) return rc;
+            if (int rc = need(h, 2, p + ".attn.proj." + std::to_string(which) + ".bias", {256}, &b)) return rc;
+            for (int hd = 0; hd < 4; ++hd)
+                for (int d = 0; d < 64; ++d) {
+                    const int nn = which * 256 + hd * 64 + d, old = d * 4 + hd;
+                    for (int k = 0; k < 256; ++k) W[nn][k] = w->data[(size_t)old * 256 + k];
+                    bias[nn] = b->data[old];
+                }
+        }
+        if (int rc = sg_linear(h, W, bias, 256, &h->sg_gnn[l].proj)) return rc;
+        // mlp.0 with merge folded in (context columns re-ordered to [head][dim]) and BatchNorm folded on top
+        const HostTensor *w0, *b0, *wm, *bm, *w3, *b3;
+        if (int rc = need(h, 2, p + ".mlp.0.weight", {512, 512, 1}, &w0)) return rc;
+        if (int rc = need(h, 2, p + ".mlp.0.bias", {512}, &b0)) return rc;
+        if (int rc = need(h, 2, p + ".attn.merge.weight", {256, 256, 1}, &wm)) return rc;
+        if (int rc = need(h, 2, p + ".attn.merge.bias", {256}, &bm)) return rc;
+        BnFold bn;
+        if (int rc = sg_bn(h, p + ".mlp.1", 512, &bn)) return rc;
+        std::vector<std::vector<double>> W0(512, std::vector<double>(512));
+        std::vector<double> bias0(512);
+        for (int n = 0; n < 512; ++n) {
+            const float* wn = w0->data.data() + (size_t)n * 512;
+            for (int k = 0; k < 256; ++k) W0[n][k] = (double)wn[k] * bn.s[n];
+            for (int hd = 0; hd < 4; ++hd)
+                for (int d = 0; d < 64; ++d) {
+                    double acc = 0.0;
+                    for (int j = 0; j < 256; ++j) acc += (double)wn[256 + j] * (double)wm->data[(size_t)j * 256 + d * 4 + hd];
+                    W0[n][256 + hd * 64 + d] = acc * bn.s[n];
+                }
+            double bb = b0->data[n];
+            for (int j = 0; j < 256; ++j) bb += (double)wn[256 + j] * (double)bm->data[j];
+            bias0[n] = bb * bn.s[n] + bn.t[n];
+        }
+        if (int rc = sg_linear(h, W0, bias0, 512, &h->sg_gnn[l].mlp0f)) return rc;
+        if (int rc = need(h, 2, p + ".mlp.3.weight", {256, 512, 1}, &w3)) return rc;
+        if (int rc = need(h, 2, p + ".mlp.3.bias", {256}, &b3)) return rc;
+        std::vector<std::vector<double>> W3(256, std::vector<double>(512));
+        std::vector<double> bias3(256);
+        for (int n = 0; n < 256; ++n) {
+            for (int k = 0; k < 512; ++k) W3[n][k] = w3->data[(size_t)n * 512 + k];
+            bias3[n] = b3->data[n];
+        }
+        if (int rc = sg_linear(h, W3, bias3, 512, &h->sg_gnn[l].mlp3)) return rc;
+    }
+    const HostTensor *wf, *bf, *bs;
+    if (int rc = need(h, 2, "final_proj.weight", {256, 256, 1}, &wf)) return rc;
+    if (int rc = need(h, 2, "final_proj.bias", {256}, &bf)) return rc;
+    if (int rc = need(h, 2, "bin_score", {1}, &bs)) return rc;
+    std::vector<std::vector<double>> Wf(256, std::vector<double>(256));
+    std::vector<double> biasf(256);
+    for (int n = 0; n < 256; ++n) {
+        for (int k = 0; k < 256; ++k) Wf[n][k] = wf->data[(size_t)n * 256 + k];
+        biasf[n] = bf->data[n];
+    }
+    if (int rc = sg_linear(h, Wf, biasf, 256, &h->sg_final)) return rc;
+    h->sg_bin = bs->data[0];
+    h->sg_layers = n_layers;
+    return 0;
+}
+
 GemmArgs lin_args(const LinLayer& L, const float* A, int lda, int M, float* C, int ldc) {
     GemmArgs g;
     g.A0 = A;
@@ -486,7 +619,7 @@ int run_detect(mg_context* h, const mg_sp_conf* conf, const float* heat, int B, 
 // ================================================================================================
 extern "C" {
 
-int mg_abi_version(void) { return 2; }
+int mg_abi_version(void) { return 3; }
 
 const char* mg_last_error(void) { return g_err.c_str(); }
 
@@ -521,12 +654,12 @@ int mg_set_precision(mg_handle h, int mode) {
 }
 
 int mg_set_weight(mg_handle h, int which, const char* key, const float* data, const int64_t* shape, int ndim) {
-    if (!h || !key || !data || which < 0 || which > 1 || ndim < 0 || (ndim > 0 && !shape)) return fail(MG_ERR_ARG, "bad argument");
+    if (!h || !key || !data || which < 0 || which > 2 || ndim < 0 || (ndim > 0 && !shape)) return fail(MG_ERR_ARG, "bad argument");
     HostTensor t;
     t.shape.assign(shape, shape + ndim);
     t.data.assign(data, data + t.numel());
     h->raw[which][key] = std::move(t);
-    if (which == 0) h->sp_variant = -1; else h->lg_layers = -1;  // re-tile on next use
+    if (which == 0) h->sp_variant = -1; else if (which == 1) h->lg_layers = -1; else h->sg_layers = -1;  // re-tile on next use
     return 0;
 }
 
@@ -534,6 +667,7 @@ int mg_weights_ready(mg_handle h, int which, int variant_or_layers) {
     if (!h) return fail(MG_ERR_ARG, "handle is NULL");
     HIPCHK(hipSetDevice(h->device));
     if (which == 0) return prepare_sp(h, variant_or_layers);
+    if (which == 2) return prepare_sg(h, variant_or_layers > 0 ? variant_or_layers : 18);
     return prepare_lg(h, variant_or_layers > 0 ? variant_or_layers : 9);
 }
 
@@ -905,6 +1039,153 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
     }
     if (ref_desc0) HIPCHK(hipMemcpyAsync(ref_desc0, X, T0 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (ref_desc1) HIPCHK(hipMemcpyAsync(ref_desc1, X + T0 * 256, T1 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
+                  const float* scores0, const float* scores1, const float* size0, const float* size1, int B, int M, int N,
+                  int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment, float* sinkhorn_cost,
+                  void* stream) {
+    if (!h || !conf || !kpts0 || !kpts1 || !desc0 || !desc1 || !scores0 || !scores1 || !size0 || !size1 || !matches0 || !matches1 ||
+        !mscores0 || !mscores1)
+        return fail(MG_ERR_ARG, "NULL argument (SuperGlue needs keypoint scores and image sizes)");
+    if (B < 1 || M < 1 || N < 1 || conf->n_layers < 1 || conf->sinkhorn_iterations < 0) return fail(MG_ERR_ARG, "bad shape / configuration");
+    HIPCHK(hipSetDevice(h->device));
+    if (int rc = prepare_sg(h, conf->n_layers)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool f16 = h->precision == MG_PREC_F16X3;
+
+    const size_t T0 = (size_t)B * M, T1 = (size_t)B * N, T = T0 + T1;
+    float* X = h->buf("lg.x", T * 256);
+    float* XS = h->buf("lg.xs", T * 256);
+    float* QKV = h->buf("lg.qkv", T * 768);
+    float* CTX = h->buf("lg.ctx", T * 256);
+    float* HID = h->buf("lg.hid", T * 512);
+    float* P0 = h->buf("lg.msg", T * 256);
+    float* SIM = h->buf("lg.sim", (size_t)B * M * N);
+    float* ST = h->buf("lg.stats", 6 * T + 16);
+    float* UV = h->buf("sg.uv", T + 2 * (size_t)B + 16);
+    if (!X || !XS || !QKV || !CTX || !HID || !P0 || !SIM || !ST || !UV) return fail(MG_ERR_HIP, "workspace allocation failed");
+
+    // one dispatcher for both arithmetic modes; "act" buffers hold SH8 in f16x3 mode and fp32 otherwise
+    struct Opt { int relu = 0; float scale = 1.f; int scale_cols = 0; const float* residual = nullptr; float* c32 = nullptr; int ldc32 = 0; };
+    auto linear = [&](const LinLayer& L, const float* A, int lda, const float* A1, int lda1, float* act_out, int ld_out, const Opt& o) {
+        if (f16) {
+            GemmF16Args g = lin_args_f16(L, A, lda, (int)T);
+            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
+            g.Cs = act_out; g.ldcs = ld_out; g.C = o.c32; g.ldc = o.ldc32;
+            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
+            launch_gemm_f16x3(g, s);
+        } else {
+            float* out = o.c32 ? o.c32 : act_out;
+            GemmArgs g = lin_args(L, A, lda, (int)T, out, o.c32 ? o.ldc32 : ld_out);
+            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
+            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
+            launch_gemm(g, s);
+        }
+    };
+    float* XA = f16 ? XS : X;  // the GEMM-input view of the descriptor stream
+
+    HIPCHK(hipMemcpyAsync(X, desc0, T0 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(X + T0 * 256, desc1, T1 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    {   // keypoint encoder: desc += MLP([x, y, score])  (superglue.py:89-103, :275-276)
+        ProfScope ps(h, s, "sg.kenc");
+        float* KIN = HID;               // (T,32) fp32, then SH8 in place of a second region
+        float* KA = HID + T * 32;
+        launch_sg_kenc_input(kpts0, kpts1, scores0, scores1, size0, size1, B, M, N, KIN, s);
+        const float* a = KIN;
+        if (f16) { launch_to_sh8(KIN, KA, (long long)T * 32, s); a = KA; }
+        Opt relu; relu.relu = 1;
+        linear(h->sg_kenc[0], a, 32, nullptr, 0, P0, 32, relu);
+        linear(h->sg_kenc[1], P0, 32, nullptr, 0, CTX, 64, relu);
+        linear(h->sg_kenc[2], CTX, 64, nullptr, 0, P0, 128, relu);
+        linear(h->sg_kenc[3], P0, 128, nullptr, 0, CTX, 256, relu);
+        Opt last; last.residual = X; last.c32 = X; last.ldc32 = 256;
+        linear(h->sg_kenc[4], CTX, 256, nullptr, 0, XS, 256, last);
+    }
+    if (int rc = tap_copy(h, "sg.kenc", X, T * 256, s)) return rc;
+
+    for (int l = 0; l < conf->n_layers; ++l) {
+        const mg_context::SgLayer& Lr = h->sg_gnn[l];
+        const int cross = l & 1;  // GNN_layers = ["self", "cross"] * 9
+        {
+            ProfScope ps(h, s, "sg.gemm.qkv");
+            Opt o; o.scale = f16 ? 0.125f * 1.4426950408889634f : 0.125f; o.scale_cols = 256;  // / sqrt(64) (x log2 e in f16x3 mode)
+            linear(Lr.proj, XA, 256, nullptr, 0, QKV, 768, o);
+        }
+        {
+            ProfScope ps(h, s, cross ? "sg.attn.cross" : "sg.attn.self");
+            if (f16) {
+                AttnF16Args a;
+                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
+                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+                launch_attention_f16x3(a, s);
+            } else {
+                AttnArgs a;
+                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
+                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+                launch_attention(a, s);
+            }
+        }
+        {
+            ProfScope ps(h, s, "sg.gemm.mlp0");
+            Opt o; o.relu = 1;
+            linear(Lr.mlp0f, XA, 256, CTX, 256, HID, 512, o);
+        }
+        {
+            ProfScope ps(h, s, "sg.gemm.mlp3");
+            Opt o; o.residual = X; o.c32 = X; o.ldc32 = 256;
+            linear(Lr.mlp3, HID, 512, nullptr, 0, XS, 256, o);
+        }
+        if (int rc = tap_copy(h, "sg.layer" + std::to_string(l), X, T * 256, s)) return rc;
+    }
+
+    float* MD = QKV;
+    {
+        ProfScope ps(h, s, "sg.gemm.final_proj");
+        Opt o;
+        linear(h->sg_final, XA, 256, nullptr, 0, MD, 256, o);
+    }
+    {
+        ProfScope ps(h, s, "sg.gemm.cost");  // scores / sqrt(256), superglue.py:283-284
+        if (f16) {
+            GemmF16Args g;
+            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
+            g.scale = 0.0625f; g.scale_cols = N;
+            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g;
+            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
+            g.scale = 0.0625f; g.scale_cols = N;
+            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
+            launch_gemm(g, s);
+        }
+    }
+    if (sinkhorn_cost) HIPCHK(hipMemcpyAsync(sinkhorn_cost, SIM, (size_t)B * M * N * sizeof(float), hipMemcpyDeviceToDevice, s));
+    {
+        ProfScope ps(h, s, "sg.sinkhorn");
+        SinkhornArgs k;
+        k.cost = SIM; k.alpha = h->sg_bin; k.B = B; k.M = M; k.N = N; k.iters = conf->sinkhorn_iterations;
+        k.u = UV; k.v = UV + (size_t)B * (M + 1);
+        k.log_assignment = log_assignment;
+        k.row_best = ST + 2 * T0; k.row_arg = reinterpret_cast<int*>(ST + 3 * T0);
+        float* cbase = ST + 4 * T0;
+        k.col_best = cbase + 2 * T1; k.col_arg = reinterpret_cast<int*>(cbase + 3 * T1);
+        launch_sinkhorn(k, s);
+        AssignArgs a;
+        a.B = B; a.M = M; a.N = N; a.threshold = conf->filter_threshold;
+        a.row_best = k.row_best; a.row_arg = k.row_arg; a.col_best = k.col_best; a.col_arg = k.col_arg;
+        a.m0 = reinterpret_cast<long long*>(matches0); a.m1 = reinterpret_cast<long long*>(matches1);
+        a.ms0 = mscores0; a.ms1 = mscores1;
+        launch_assign_filter(a, s);
+    }
     HIPCHK(hipGetLastError());
     return 0;
 }

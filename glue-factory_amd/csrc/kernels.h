@@ -199,3 +199,21 @@ struct AssignArgs {
     float* ms1 = nullptr;
 };
 void launch_assignment(const AssignArgs& a, hipStream_t s);
+
+// ---- sg_misc.hip : SuperGlue keypoint-encoder input + log-domain Sinkhorn ---------------------------
+void launch_sg_kenc_input(const float* k0, const float* k1, const float* s0, const float* s1, const float* size0, const float* size1, int B,
+                          int M, int N, float* out, hipStream_t s);
+struct SinkhornArgs {
+    const float* cost = nullptr;  // (B,M,N)
+    float alpha = 1.f;            // bin score
+    int B = 0, M = 0, N = 0, iters = 50;
+    float* u = nullptr;           // (B,M+1) workspace
+    float* v = nullptr;           // (B,N+1)
+    float* log_assignment = nullptr;  // optional (B,M+1,N+1)
+    float* row_best = nullptr;    // (B,M)
+    int* row_arg = nullptr;
+    float* col_best = nullptr;    // (B,N)
+    int* col_arg = nullptr;
+};
+void launch_sinkhorn(const SinkhornArgs& a, hipStream_t s);
+void launch_assign_filter(const AssignArgs& a, hipStream_t s);

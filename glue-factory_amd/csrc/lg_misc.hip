@@ -284,3 +284,8 @@ void launch_assignment(const AssignArgs& a, hipStream_t s) {
     const int L = a.M > a.N ? a.M : a.N;
     hipLaunchKernelGGL(assign_filter, dim3((L + 255) / 256, a.B), dim3(256), 0, s, a);
 }
+
+void launch_assign_filter(const AssignArgs& a, hipStream_t s) {
+    const int L = a.M > a.N ? a.M : a.N;
+    hipLaunchKernelGGL(assign_filter, dim3((L + 255) / 256, a.B), dim3(256), 0, s, a);
+}

@@ -20,7 +20,7 @@ MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN = 0, 1, 2
 # every symbol include/matchglue.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_precision", "mg_set_weight", "mg_weights_ready",
-    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_debug_request", "mg_debug_read",
+    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_sg_forward", "mg_debug_request", "mg_debug_read",
     "mg_profile_enable", "mg_profile_read", "mg_test_linear",
 ]
 
@@ -38,6 +38,10 @@ class SpConf(Structure):
 
 class LgConf(Structure):
     _fields_ = [("n_layers", c_int32), ("num_heads", c_int32), ("filter_threshold", c_float)]
+
+
+class SgConf(Structure):
+    _fields_ = [("n_layers", c_int32), ("sinkhorn_iterations", c_int32), ("filter_threshold", c_float)]
 
 
 _lib = None
@@ -66,6 +70,7 @@ def lib():
                                c_void_p, c_void_p]
     L.mg_sp_sample.argtypes = [c_void_p, POINTER(SpConf), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.mg_lg_forward.argtypes = [c_void_p, POINTER(LgConf)] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 8
+    L.mg_sg_forward.argtypes = [c_void_p, POINTER(SgConf)] + [c_void_p] * 8 + [c_int] * 3 + [c_void_p] * 7
     L.mg_debug_request.argtypes = [c_void_p, c_char_p]
     L.mg_debug_read.argtypes = [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]
     L.mg_profile_enable.argtypes = [c_void_p, c_int]
@@ -198,6 +203,28 @@ class Engine:
         _check(lib().mg_lg_forward(self._h, ctypes.byref(conf), _ptr(k0), _ptr(k1), _ptr(d0), _ptr(d1), _ptr(s0), _ptr(s1), B, M, N,
                                    _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1), _ptr(la), _ptr(r0), _ptr(r1), _stream(dev)))
         return m0, m1, ms0, ms1, la, r0, r1
+
+    # -- SuperGlue -------------------------------------------------------------------------------
+    def sg_forward(self, conf, k0, k1, d0, d1, sc0, sc1, size0, size1, want_log_assignment=True, want_cost=True):
+        dev = self.device
+        k0, k1, d0, d1, sc0, sc1 = (_f32(t, dev) for t in (k0, k1, d0, d1, sc0, sc1))
+        B, M, _ = k0.shape
+        N = k1.shape[1]
+        if d0.shape != (B, M, 256) or d1.shape != (B, N, 256):
+            raise RuntimeError(f"descriptors must be (B,K,256); got {tuple(d0.shape)} / {tuple(d1.shape)}")
+        if sc0.shape != (B, M) or sc1.shape != (B, N):
+            raise RuntimeError(f"keypoint scores must be (B,K); got {tuple(sc0.shape)} / {tuple(sc1.shape)}")
+        s0 = _f32(size0, dev).reshape(-1, 2).expand(B, 2).contiguous()
+        s1 = _f32(size1, dev).reshape(-1, 2).expand(B, 2).contiguous()
+        m0 = torch.empty(B, M, dtype=torch.int64, device=dev)
+        m1 = torch.empty(B, N, dtype=torch.int64, device=dev)
+        ms0 = torch.empty(B, M, device=dev)
+        ms1 = torch.empty(B, N, device=dev)
+        la = torch.empty(B, M + 1, N + 1, device=dev) if want_log_assignment else None
+        cost = torch.empty(B, M, N, device=dev) if want_cost else None
+        _check(lib().mg_sg_forward(self._h, ctypes.byref(conf), _ptr(k0), _ptr(k1), _ptr(d0), _ptr(d1), _ptr(sc0), _ptr(sc1), _ptr(s0),
+                                   _ptr(s1), B, M, N, _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1), _ptr(la), _ptr(cost), _stream(dev)))
+        return m0, m1, ms0, ms1, la, cost
 
     # -- introspection ---------------------------------------------------------------------------
     def debug_request(self, tap):

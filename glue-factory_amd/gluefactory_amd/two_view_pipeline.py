@@ -17,6 +17,7 @@ _ALIASES = {
     "gluefactory.models.extractors.superpoint_open": "gluefactory_amd.superpoint_open",
     "matchers.lightglue": "gluefactory_amd.lightglue",
     "gluefactory.models.matchers.lightglue": "gluefactory_amd.lightglue",
+    "gluefactory_nonfree.superglue": "gluefactory_amd.superglue",
 }
 
 

@@ -77,7 +77,7 @@ int mg_set_precision(mg_handle h, int mode);
  * Upload one tensor of a reference state_dict, addressed by its reference key name
  * ("conv1a.weight", "backbone.0.0.bn.running_var", "transformers.3.self_attn.Wqkv.weight", ...).
  * `data` is a HOST pointer to contiguous fp32 in the reference's own layout (OIHW / [out][in]);
- * the library re-tiles it for the kernels.  `which` selects the model: 0 = SuperPoint, 1 = LightGlue.
+ * the library re-tiles it for the kernels.  `which` selects the model: 0 = SuperPoint, 1 = LightGlue, 2 = SuperGlue.
  * mg_weights_ready() re-tiles and uploads; it returns 0 once every tensor the model needs has
  * arrived.  `variant_or_layers` is the mg_sp_variant for which == 0 and n_layers for which == 1. */
 int mg_set_weight(mg_handle h, int which, const char* key, const float* data, const int64_t* shape, int ndim);
@@ -119,6 +119,24 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
                   const float* desc0, const float* desc1, const float* size0, const float* size1,
                   int B, int M, int N, int64_t* matches0, int64_t* matches1, float* mscores0,
                   float* mscores1, float* log_assignment, float* ref_desc0, float* ref_desc1, void* stream);
+
+/* -- SuperGlue -------------------------------------------------------------
+ * gluefactory_nonfree/superglue.py:253-307: keypoint encoder (MLP on (x,y,score)), 18-layer attentional
+ * GNN (self/cross alternating), final projection, log-domain Sinkhorn with a dustbin, mutual filter.
+ * Weights: mg_set_weight(h, 2, key, ...) with the reference key names ("kenc.encoder.0.weight",
+ * "gnn.layers.3.attn.proj.1.bias", "bin_score", ...), then mg_weights_ready(h, 2, n_layers).
+ * scores0/1 (B,M)/(B,N) keypoint scores; size0/1 (B,2) (w,h) REQUIRED (superglue.py:268-273).
+ * log_assignment optional (B,M+1,N+1); sinkhorn_cost optional (B,M,N). */
+typedef struct mg_sg_conf {
+    int32_t n_layers;            /* 18 */
+    int32_t sinkhorn_iterations; /* 50 */
+    float filter_threshold;
+} mg_sg_conf;
+int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const float* kpts1,
+                  const float* desc0, const float* desc1, const float* scores0, const float* scores1,
+                  const float* size0, const float* size1, int B, int M, int N, int64_t* matches0,
+                  int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment,
+                  float* sinkhorn_cost, void* stream);
 
 /* -- introspection ----------------------------------------------------------------------------
  * Copy a named internal buffer of the LAST forward into `dst` (device, fp32), for stage-wise
