@@ -64,11 +64,16 @@ def algorithmic_flops(B):
         # cross = one shared similarity + two PV products (the reference computes sim once, lightglue.py:201)
         "lg.attn.self": 2 * (2.0 * 4 * K * K * 64) * 2 * B,
         "lg.attn.cross": 3 * (2.0 * 4 * K * K * 64) * B,
+        # SuperGlue (BASELINE.json configs[3]): same linear shapes; cross layers attend in both directions
+        # with separate similarities (superglue.py:118-141), so self and cross cost the same
+        "sg.gemm.qkv": lin(256, 768), "sg.gemm.mlp0": lin(512, 512), "sg.gemm.mlp3": lin(512, 256),
+        "sg.gemm.final_proj": lin(256, 256), "sg.gemm.cost": 2.0 * B * K * K * 256,
+        "sg.attn.self": 2 * (2.0 * 4 * K * K * 64) * 2 * B, "sg.attn.cross": 2 * (2.0 * 4 * K * K * 64) * 2 * B,
     }
     return f
 
 
-def cpu_baseline(pairs=4):
+def cpu_baseline(pairs=4, matcher="lightglue"):
     """The CPU oracle (oracle/sp_lg_oracle.py, a restatement of the reference) on a bounded sample."""
     from oracle import sp_lg_oracle as O
 
@@ -76,7 +81,8 @@ def cpu_baseline(pairs=4):
     # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribe it
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
-    W_sp, W_lg = O.make_sp_weights(0), O.make_lg_weights(7, final_gain=8.0, match_bias=2.0)
+    W_sp = O.make_sp_weights(0)
+    W_lg = O.make_lg_weights(7, final_gain=8.0, match_bias=2.0) if matcher == "lightglue" else O.make_sg_weights(9)
     im = synthetic_images(2 * pairs, 123)
     size = torch.tensor([[float(W), float(H)]])
     spc = dict(nms_radius=3, detection_threshold=0.0, max_num_keypoints=K)
@@ -85,7 +91,11 @@ def cpu_baseline(pairs=4):
     while n < pairs or (time.perf_counter() - t0 < 10.0 and n < 64):
         i = n % pairs
         data = {"view0": {"image": im[2 * i: 2 * i + 1], "image_size": size}, "view1": {"image": im[2 * i + 1: 2 * i + 2], "image_size": size}}
-        O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1))
+        if matcher == "lightglue":
+            O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1))
+        else:
+            p0, p1 = O.superpoint_forward(data["view0"], W_sp, **spc), O.superpoint_forward(data["view1"], W_sp, **spc)
+            O.superglue_forward({**{k + "0": v for k, v in p0.items()}, **{k + "1": v for k, v in p1.items()}, **data}, W_lg)
         n += 1
     dt = time.perf_counter() - t0
     pairs = n
@@ -94,6 +104,7 @@ def cpu_baseline(pairs=4):
 
 
 def main():
+    global K
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -102,7 +113,11 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="f32: fp32-input MFMA; f16x3: split-fp16 operands on the f16 MFMA (default, fp32-class accuracy)")
+    ap.add_argument("--matcher", default="lightglue", choices=["lightglue", "superglue"],
+                    help="lightglue: the north-star workload (configs[1]); superglue: configs[3] (use --kpts 2048)")
+    ap.add_argument("--kpts", type=int, default=K, help="keypoints per image")
     args = ap.parse_args()
+    K = args.kpts
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -124,10 +139,14 @@ def main():
         "extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": K, "nms_radius": 3,
                       "detection_threshold": 0.0, "remove_borders": 4, "force_num_keypoints": True, "sync_free": True,
                       "precision": args.precision},
-        "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "precision": args.precision},
+        "matcher": ({"name": "matchers.lightglue", "filter_threshold": 0.1, "precision": args.precision}
+                    if args.matcher == "lightglue" else
+                    {"name": "gluefactory_nonfree.superglue", "filter_threshold": 0.2, "precision": args.precision,
+                     "return_log_assignment": False}),
     }).eval()
     pipe.extractor.load_state_dict(O.make_sp_weights(0))
-    pipe.matcher.load_state_dict(O.make_lg_weights(7, final_gain=8.0, match_bias=2.0))
+    pipe.matcher.load_state_dict(O.make_lg_weights(7, final_gain=8.0, match_bias=2.0) if args.matcher == "lightglue"
+                                 else O.make_sg_weights(9))
 
     im = synthetic_images(2 * B, 1000 + rank).to(dev)
     size = torch.tensor([[float(W), float(H)]] * B, device=dev)
@@ -191,12 +210,13 @@ def main():
         # command (profiles/summarize_pmc.py; FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE), not live
         traffic, traffic_src = None, None
         tpath = os.path.join(ROOT, "profiles", f"r01_c_{args.precision}_hbm_traffic.json")
-        if os.path.exists(tpath) and B == PAIRS:
+        if os.path.exists(tpath) and B == PAIRS and args.matcher == "lightglue" and K == 1024:
             tj = json.load(open(tpath))
             if dom in tj:
                 traffic, traffic_src = tj[dom]["hbm_bytes_per_launch"], os.path.relpath(tpath, ROOT)
         res = {
-            "metric": "image-pairs/sec SP+LightGlue (VGA, 1024 kpts) at 1/2/4/8 MI355X",
+            "metric": ("image-pairs/sec SP+LightGlue (VGA, 1024 kpts) at 1/2/4/8 MI355X" if args.matcher == "lightglue" and K == 1024
+                       else f"image-pairs/sec SP+{args.matcher} (VGA, {K} kpts)"),
             "value": round(world * B * args.steps / dt, 3),
             "unit": "pairs/s",
             "n_gpus": world,
@@ -208,7 +228,9 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": f"SuperPoint + LightGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[1])",
+            "config": {"workload": (f"SuperPoint + LightGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[1])"
+                                    if args.matcher == "lightglue" else
+                                    f"SuperPoint + SuperGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[3])"),
                        "pairs_per_gpu": B, "global_pairs": B * world, "parallelism": f"dp{world}", "matches_per_step_rank0": nvalid,
                        "arithmetic": ("fp32 storage, fp32-input MFMA, fp32 accumulate" if args.precision == "f32" else
                                       "fp32-equivalent split-fp16 storage (hi+lo), f16 MFMA x3 products, fp32 accumulate")},
@@ -222,7 +244,7 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on a bounded sample (10-30 s)")
-            res["cpu_baseline"] = cpu_baseline()
+            res["cpu_baseline"] = cpu_baseline(matcher=args.matcher)
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()

@@ -1066,7 +1066,7 @@ int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const
     float* P0 = h->buf("lg.msg", T * 256);
     float* SIM = h->buf("lg.sim", (size_t)B * M * N);
     float* ST = h->buf("lg.stats", 6 * T + 16);
-    float* UV = h->buf("sg.uv", T + 2 * (size_t)B + 16);
+    float* UV = h->buf("sg.uv", sinkhorn_work_floats(B, M, N));
     if (!X || !XS || !QKV || !CTX || !HID || !P0 || !SIM || !ST || !UV) return fail(MG_ERR_HIP, "workspace allocation failed");
 
     // one dispatcher for both arithmetic modes; "act" buffers hold SH8 in f16x3 mode and fp32 otherwise
@@ -1173,7 +1173,7 @@ int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const
         ProfScope ps(h, s, "sg.sinkhorn");
         SinkhornArgs k;
         k.cost = SIM; k.alpha = h->sg_bin; k.B = B; k.M = M; k.N = N; k.iters = conf->sinkhorn_iterations;
-        k.u = UV; k.v = UV + (size_t)B * (M + 1);
+        k.work = UV;
         k.log_assignment = log_assignment;
         k.row_best = ST + 2 * T0; k.row_arg = reinterpret_cast<int*>(ST + 3 * T0);
         float* cbase = ST + 4 * T0;

@@ -207,13 +207,13 @@ struct SinkhornArgs {
     const float* cost = nullptr;  // (B,M,N)
     float alpha = 1.f;            // bin score
     int B = 0, M = 0, N = 0, iters = 50;
-    float* u = nullptr;           // (B,M+1) workspace
-    float* v = nullptr;           // (B,N+1)
+    float* work = nullptr;        // sinkhorn_work_floats(B,M,N) floats: u, v and the column partials
     float* log_assignment = nullptr;  // optional (B,M+1,N+1)
     float* row_best = nullptr;    // (B,M)
     int* row_arg = nullptr;
     float* col_best = nullptr;    // (B,N)
     int* col_arg = nullptr;
 };
+size_t sinkhorn_work_floats(int B, int M, int N);
 void launch_sinkhorn(const SinkhornArgs& a, hipStream_t s);
 void launch_assign_filter(const AssignArgs& a, hipStream_t s);

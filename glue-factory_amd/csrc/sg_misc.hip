@@ -37,55 +37,272 @@ struct SinkArgs {
     float alpha;
     int B, M, N;
     float* u;  // (B, M+1)
-    float* v;  // (B, N+1)
+    float* v;  // (B, vstride)
+    int vstride;  // roundup4(N+1): 16-byte aligned v vectors
     float norm, log_mu_bin, log_nu_bin;  // -log(M+N), log(N)+norm, log(M)+norm
 };
 
-// u[i] = log_mu[i] - logsumexp_j(Z[i,j] + v[j]).  One wave per row (rows 0..M of every pair).
+// u[i] = log_mu[i] - logsumexp_j(Z[i,j] + v[j]).  One wave per row (rows 0..M of every pair).  A row of up to
+// 2048 couplings stays in registers (8 x 16-byte loads per lane, all in flight together), so the matrix is read
+// once per half-iteration; longer or unaligned rows take the two-pass loop (second pass served by the cache).
 __global__ __launch_bounds__(256) void sinkhorn_rows_kernel(const SinkArgs p) {
     const int lane = threadIdx.x & 63;
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long long)p.B * (p.M + 1)) return;
     const int b = (int)(row / (p.M + 1)), i = (int)(row - (long long)b * (p.M + 1));
-    const float* v = p.v + (long long)b * (p.N + 1);
+    const float* v = p.v + (long long)b * p.vstride;
     const float* c = p.cost + ((long long)b * p.M + i) * p.N;
-    float m = -__builtin_inff();
-    for (int j = lane; j <= p.N; j += 64) {
-        const float z = (i < p.M && j < p.N) ? c[j] : p.alpha;
-        m = fmaxf(m, z + v[j]);
-    }
-    m = wave_max(m);
-    float s = 0.f;
-    for (int j = lane; j <= p.N; j += 64) {
-        const float z = (i < p.M && j < p.N) ? c[j] : p.alpha;
-        s += expf(z + v[j] - m);
+    float m, s;
+    if (i < p.M && (p.N & 3) == 0 && p.N <= 2048) {
+        f32x4 x[8];
+        const int nq = p.N >> 2;  // float4 groups in the row
+        m = (lane == 0) ? p.alpha + v[p.N] : -__builtin_inff();  // dustbin column
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+            const int q = lane + 64 * k;
+            if (q < nq) {
+                x[k] = *reinterpret_cast<const f32x4*>(c + 4 * q);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) x[k][e] += v[4 * q + e];
+                m = fmaxf(m, fmaxf(fmaxf(x[k][0], x[k][1]), fmaxf(x[k][2], x[k][3])));
+            }
+        }
+        m = wave_max(m);
+        s = (lane == 0) ? expf(p.alpha + v[p.N] - m) : 0.f;
+#pragma unroll
+        for (int k = 0; k < 8; ++k)
+            if (lane + 64 * k < nq) s += (expf(x[k][0] - m) + expf(x[k][1] - m)) + (expf(x[k][2] - m) + expf(x[k][3] - m));
+    } else {
+        m = -__builtin_inff();
+        for (int j = lane; j <= p.N; j += 64) {
+            const float z = (i < p.M && j < p.N) ? c[j] : p.alpha;
+            m = fmaxf(m, z + v[j]);
+        }
+        m = wave_max(m);
+        s = 0.f;
+        for (int j = lane; j <= p.N; j += 64) {
+            const float z = (i < p.M && j < p.N) ? c[j] : p.alpha;
+            s += expf(z + v[j] - m);
+        }
     }
     s = wave_sum(s);
     if (lane == 0) p.u[row] = (i < p.M ? p.norm : p.log_mu_bin) - (logf(s) + m);
 }
 
-// v[j] = log_nu[j] - logsumexp_i(Z[i,j] + u[i]).  64 columns per block, 4 row groups, online max/sum.
-__global__ __launch_bounds__(256) void sinkhorn_cols_kernel(const SinkArgs p) {
-    __shared__ float s_m[4][64], s_l[4][64];
+// v[j] = log_nu[j] - logsumexp_i(Z[i,j] + u[i]).  64 columns per block (a wave reads 256 contiguous bytes of a
+// row), 8 waves take interleaved rows in batches of 8 independent loads with one running (max, sum) pair per
+// lane: 9 exponentials per 8 couplings, 16 KB in flight per workgroup.
+constexpr int COLS_WAVES = 8, COLS_BATCH = 8;
+__global__ __launch_bounds__(64 * COLS_WAVES) void sinkhorn_cols_kernel(const SinkArgs p) {
+    __shared__ float s_m[COLS_WAVES][64], s_l[COLS_WAVES][64];
     const int b = blockIdx.y, cl = threadIdx.x & 63, j = blockIdx.x * 64 + cl, g = threadIdx.x >> 6;
     const float* u = p.u + (long long)b * (p.M + 1);
     const float* c = p.cost + (long long)b * p.M * p.N;
     float m = -__builtin_inff(), l = 0.f;
-    if (j <= p.N)
-        for (int i = g; i <= p.M; i += 4) {
-            const float z = (i < p.M && j < p.N) ? c[(long long)i * p.N + j] : p.alpha;
-            const float x = z + u[i];
-            if (x > m) { l = l * expf(m - x) + 1.f; m = x; } else { l += expf(x - m); }
+    if (j <= p.N) {
+        const bool inner = j < p.N;
+        const float* cj = c + (inner ? j : 0);
+        // rows i = g + COLS_WAVES * t; the last row (i == M) is the dustbin row
+        for (int i0 = g; i0 <= p.M; i0 += COLS_WAVES * COLS_BATCH) {
+            float x[COLS_BATCH];
+#pragma unroll
+            for (int k = 0; k < COLS_BATCH; ++k) {
+                const int i = i0 + COLS_WAVES * k;
+                x[k] = -__builtin_inff();
+                if (i <= p.M) x[k] = ((inner && i < p.M) ? cj[(long long)i * p.N] : p.alpha) + u[i];
+            }
+            float bm = x[0];
+#pragma unroll
+            for (int k = 1; k < COLS_BATCH; ++k) bm = fmaxf(bm, x[k]);
+            const float nm = fmaxf(m, bm);  // finite: every batch holds at least row i0
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < COLS_BATCH; ++k) acc += expf(x[k] - nm);  // exp(-inf) = 0 for the padding
+            l = l * expf(m - nm) + acc;
+            m = nm;
         }
+    }
+    s_m[g][cl] = m;
+    s_l[g][cl] = l;
+    __syncthreads();
+    if (g == 0 && j <= p.N) {
+        float mm = s_m[0][cl];
+#pragma unroll
+        for (int k = 1; k < COLS_WAVES; ++k) mm = fmaxf(mm, s_m[k][cl]);
+        float ll = 0.f;
+#pragma unroll
+        for (int k = 0; k < COLS_WAVES; ++k)
+            if (s_l[k][cl] > 0.f) ll += s_l[k][cl] * expf(s_m[k][cl] - mm);
+        p.v[(long long)b * p.vstride + j] = (j < p.N ? p.norm : p.log_nu_bin) - (logf(ll) + mm);
+    }
+}
+
+// ---- fused iteration (N % 4 == 0, N <= 2048; v stride padded to a multiple of 4) -----------------------------
+// One launch per Sinkhorn iteration reads the couplings ONCE: a workgroup owns 16 consecutive rows (4 waves x 4
+// rows, a row = 8 x 16 bytes per lane held in registers, all 32 loads of a lane in flight together).  Row
+// half-step: u_i from the registers.  Column half-step: with its own fresh u_i every wave reduces its 4 rows to
+// one (max, sum) pair per column, the 4 waves combine through LDS and the workgroup writes ONE partial per column;
+// sinkhorn_combine_kernel folds the ceil((M+1)/16) partials of a column into v_j.  Two workgroups share a CU
+// (66 KB LDS, 232 VGPRs each), so one's load phase runs under the other's exponentials.
+constexpr int FW = 4, FR = 4 * FW;  // waves per workgroup, rows per workgroup
+struct SinkFusedArgs {
+    SinkArgs a;
+    int nblk;      // row blocks per pair
+    float* pm;     // (B, nblk, vstride) partial column maxima
+    float* pl;     // (B, nblk, vstride) partial column sums
+};
+
+// exp(x) for x <= 0 on the hardware exp2 (1 ulp); the product rounds x * log2(e) to 6e-8 relative, i.e. < 2e-6
+// relative on every term that is not already negligible (x > -30)
+__device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
+
+__global__ __launch_bounds__(64 * FW, 2) void sinkhorn_fused_kernel(const SinkFusedArgs q) {
+    const SinkArgs& p = q.a;
+    __shared__ float s_m[FW][2052], s_l[FW][2052];
+    const int t = threadIdx.x, lane = t & 63, w = t >> 6;
+    const int b = blockIdx.y, blk = blockIdx.x;
+    const int nq = p.N >> 2;
+    const float* v = p.v + (long long)b * p.vstride;
+    const float* c = p.cost + (long long)b * p.M * p.N;
+    float* u = p.u + (long long)b * (p.M + 1);
+    const float vbin = v[p.N];
+
+    f32x4 z[4][8];
+    float ui[4];
+    bool live[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = blk * FR + w + FW * k;
+        live[k] = i <= p.M;
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int qd = lane + 64 * g;
+            z[k][g] = f32x4{p.alpha, p.alpha, p.alpha, p.alpha};
+            if (i < p.M && qd < nq) z[k][g] = *reinterpret_cast<const f32x4*>(c + (long long)i * p.N + 4 * qd);
+        }
+    }
+    // row half-step
+    {
+        f32x4 vv[8];
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            const int qd = lane + 64 * g;
+            vv[g] = qd < nq ? *reinterpret_cast<const f32x4*>(v + 4 * qd) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            float m = (lane == 0) ? p.alpha + vbin : -__builtin_inff();
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (lane + 64 * g < nq) {
+                    const f32x4 x = z[k][g] + vv[g];
+                    m = fmaxf(m, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+                }
+            m = wave_max(m);
+            float s = (lane == 0) ? fexp(p.alpha + vbin - m) : 0.f;
+#pragma unroll
+            for (int g = 0; g < 8; ++g)
+                if (lane + 64 * g < nq) {
+                    const f32x4 x = z[k][g] + vv[g];
+                    s += (fexp(x[0] - m) + fexp(x[1] - m)) + (fexp(x[2] - m) + fexp(x[3] - m));
+                }
+            s = wave_sum(s);
+            const int i = blk * FR + w + FW * k;
+            ui[k] = (i < p.M ? p.norm : p.log_mu_bin) - (logf(s) + m);
+            if (lane == 0 && live[k]) u[i] = ui[k];
+        }
+    }
+    // column half-step over this wave's rows
+    const float NEG = -__builtin_inff();
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {
+        const int qd = lane + 64 * g;
+        if (qd >= nq) continue;
+        f32x4 cm = {NEG, NEG, NEG, NEG};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (live[k])
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cm[e] = fmaxf(cm[e], z[k][g][e] + ui[k]);
+        f32x4 cl = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (live[k])
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cl[e] += fexp(z[k][g][e] + ui[k] - cm[e]);
+        *reinterpret_cast<f32x4*>(&s_m[w][4 * qd]) = cm;
+        *reinterpret_cast<f32x4*>(&s_l[w][4 * qd]) = cl;
+    }
+    if (lane == 0) {  // dustbin column: alpha in every row
+        float cm = NEG, cl = 0.f;
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (live[k]) cm = fmaxf(cm, p.alpha + ui[k]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (live[k]) cl += fexp(p.alpha + ui[k] - cm);
+        s_m[w][p.N] = cm;
+        s_l[w][p.N] = cl;
+    }
+    __syncthreads();
+    float* pm = q.pm + ((long long)b * q.nblk + blk) * p.vstride;
+    float* pl = q.pl + ((long long)b * q.nblk + blk) * p.vstride;
+    for (int j = t; j <= p.N; j += 64 * FW) {
+        float mm = s_m[0][j];
+#pragma unroll
+        for (int k = 1; k < FW; ++k) mm = fmaxf(mm, s_m[k][j]);
+        float ll = 0.f;
+#pragma unroll
+        for (int k = 0; k < FW; ++k)
+            if (s_l[k][j] > 0.f) ll += s_l[k][j] * fexp(s_m[k][j] - mm);
+        pm[j] = mm;
+        pl[j] = ll;
+    }
+}
+
+// v_j = log_nu_j - logsumexp over the row-block partials of column j.  64 columns per workgroup, 4 waves take
+// interleaved blocks in batches of 8 independent loads.
+__global__ __launch_bounds__(256) void sinkhorn_combine_kernel(const SinkFusedArgs q) {
+    const SinkArgs& p = q.a;
+    __shared__ float s_m[4][64], s_l[4][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, j = blockIdx.x * 64 + cl, g = threadIdx.x >> 6;
+    float m = -__builtin_inff(), l = 0.f;
+    if (j <= p.N) {
+        const float* pm = q.pm + (long long)b * q.nblk * p.vstride + j;
+        const float* pl = q.pl + (long long)b * q.nblk * p.vstride + j;
+        for (int k0 = g; k0 < q.nblk; k0 += 32) {
+            float xm[8], xl[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int k = k0 + 4 * e;
+                xm[e] = -__builtin_inff();
+                xl[e] = 0.f;
+                if (k < q.nblk) {
+                    xm[e] = pm[(long long)k * p.vstride];
+                    xl[e] = pl[(long long)k * p.vstride];
+                }
+            }
+            float nm = m;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) nm = fmaxf(nm, xm[e]);
+            float acc = l > 0.f ? l * fexp(m - nm) : 0.f;
+#pragma unroll
+            for (int e = 0; e < 8; ++e)
+                if (xl[e] > 0.f) acc += xl[e] * fexp(xm[e] - nm);
+            l = acc;
+            m = nm;
+        }
+    }
     s_m[g][cl] = m;
     s_l[g][cl] = l;
     __syncthreads();
     if (g == 0 && j <= p.N) {
         const float mm = fmaxf(fmaxf(s_m[0][cl], s_m[1][cl]), fmaxf(s_m[2][cl], s_m[3][cl]));
         float ll = 0.f;
+#pragma unroll
         for (int k = 0; k < 4; ++k)
-            if (s_l[k][cl] > 0.f) ll += s_l[k][cl] * expf(s_m[k][cl] - mm);
-        p.v[(long long)b * (p.N + 1) + j] = (j < p.N ? p.norm : p.log_nu_bin) - (logf(ll) + mm);
+            if (s_l[k][cl] > 0.f) ll += s_l[k][cl] * fexp(s_m[k][cl] - mm);
+        p.v[(long long)b * p.vstride + j] = (j < p.N ? p.norm : p.log_nu_bin) - (logf(ll) + mm);
     }
 }
 
@@ -95,7 +312,7 @@ __global__ __launch_bounds__(256) void sinkhorn_final_rows(const SinkArgs p, flo
     const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= (long long)p.B * (p.M + 1)) return;
     const int b = (int)(row / (p.M + 1)), i = (int)(row - (long long)b * (p.M + 1));
-    const float* v = p.v + (long long)b * (p.N + 1);
+    const float* v = p.v + (long long)b * p.vstride;
     const float* c = p.cost + ((long long)b * p.M + i) * p.N;
     const float ui = p.u[row];
     float* o = la ? la + row * (p.N + 1) : nullptr;
@@ -129,7 +346,7 @@ __global__ __launch_bounds__(256) void sinkhorn_final_cols(const SinkArgs p, flo
     float best = -__builtin_inff();
     int arg = 0x7fffffff;
     if (j < p.N) {
-        const float vj = p.v[(long long)b * (p.N + 1) + j];
+        const float vj = p.v[(long long)b * p.vstride + j];
         for (int i = g; i < p.M; i += 4) {
             const float x = __fsub_rn(__fadd_rn(__fadd_rn(c[(long long)i * p.N + j], u[i]), vj), p.norm);
             if (x > best) { best = x; arg = i; }
@@ -154,20 +371,41 @@ void launch_sg_kenc_input(const float* k0, const float* k1, const float* s0, con
     hipLaunchKernelGGL(sg_kenc_input_kernel, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, k0, k1, s0, s1, size0, size1, B, M, N, out);
 }
 
+size_t sinkhorn_work_floats(int B, int M, int N) {
+    const size_t vs = (size_t)(N + 4) / 4 * 4, nblk = (size_t)(M + 1 + FR - 1) / FR;
+    return (size_t)B * (M + 1) + (size_t)B * vs + 2 * (size_t)B * nblk * vs + 16;
+}
+
 void launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
     SinkArgs p;
-    p.cost = a.cost; p.alpha = a.alpha; p.B = a.B; p.M = a.M; p.N = a.N; p.u = a.u; p.v = a.v;
+    p.cost = a.cost; p.alpha = a.alpha; p.B = a.B; p.M = a.M; p.N = a.N;
+    p.vstride = (a.N + 4) / 4 * 4;
+    p.u = a.work;
+    p.v = a.work + (size_t)a.B * (a.M + 1);
     p.norm = -logf((float)a.M + (float)a.N);
     p.log_mu_bin = logf((float)a.N) + p.norm;
     p.log_nu_bin = logf((float)a.M) + p.norm;
-    (void)hipMemsetAsync(a.u, 0, sizeof(float) * a.B * (a.M + 1), s);
-    (void)hipMemsetAsync(a.v, 0, sizeof(float) * a.B * (a.N + 1), s);
+    (void)hipMemsetAsync(p.v, 0, sizeof(float) * a.B * p.vstride, s);
     const long long rows = (long long)a.B * (a.M + 1);
     const dim3 rgrid((unsigned)((rows + 3) / 4)), cgrid((a.N + 1 + 63) / 64, a.B);
-    for (int it = 0; it < a.iters; ++it) {
-        hipLaunchKernelGGL(sinkhorn_rows_kernel, rgrid, dim3(256), 0, s, p);
-        hipLaunchKernelGGL(sinkhorn_cols_kernel, cgrid, dim3(256), 0, s, p);
+    const bool fused = (a.N & 3) == 0 && a.N <= 2048 && (reinterpret_cast<uintptr_t>(a.cost) & 15) == 0;
+    if (fused) {
+        SinkFusedArgs q;
+        q.a = p;
+        q.nblk = (a.M + 1 + FR - 1) / FR;
+        q.pm = p.v + (size_t)a.B * p.vstride;
+        q.pl = q.pm + (size_t)a.B * q.nblk * p.vstride;
+        for (int it = 0; it < a.iters; ++it) {
+            hipLaunchKernelGGL(sinkhorn_fused_kernel, dim3(q.nblk, a.B), dim3(64 * FW), 0, s, q);
+            hipLaunchKernelGGL(sinkhorn_combine_kernel, dim3((a.N + 1 + 63) / 64, a.B), dim3(256), 0, s, q);
+        }
+    } else {
+        for (int it = 0; it < a.iters; ++it) {
+            hipLaunchKernelGGL(sinkhorn_rows_kernel, rgrid, dim3(256), 0, s, p);
+            hipLaunchKernelGGL(sinkhorn_cols_kernel, cgrid, dim3(64 * COLS_WAVES), 0, s, p);
+        }
     }
+    if (a.iters == 0) (void)hipMemsetAsync(p.u, 0, sizeof(float) * a.B * (a.M + 1), s);
     hipLaunchKernelGGL(sinkhorn_final_rows, rgrid, dim3(256), 0, s, p, a.log_assignment, a.row_best, a.row_arg);
     hipLaunchKernelGGL(sinkhorn_final_cols, dim3((a.N + 63) / 64, a.B), dim3(256), 0, s, p, a.col_best, a.col_arg);
 }

@@ -1,0 +1,19 @@
+#!/bin/bash
+# Kernel-trace + stats pass of one bench.py command on the GPU box (run through gpurun from the repo root):
+#   profiles/run_kernel_trace.sh <tag> [bench.py args...]
+# writes gpurun_out/<tag>_kernel_stats.csv; copy the summary into profiles/ to have it judged.
+set -e
+tag=$1; shift
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+mkdir -p "$root/gpurun_out"
+cd /tmp && export TMPDIR=/tmp
+timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/prof_$tag" -o "$tag" -- \
+    python3 "$root/bench.py" --no-cpu-baseline "$@" > "$root/gpurun_out/${tag}_prof.log" 2>&1
+f=$(find "$root/gpurun_out/prof_$tag" -name "*kernel_stats.csv" | head -1)
+cut -c1-240 "$f" > "$root/gpurun_out/${tag}_kernel_stats.csv"
+python3 - "$root/gpurun_out/${tag}_kernel_stats.csv" <<'PY'
+import csv, sys
+rows = list(csv.DictReader(open(sys.argv[1])))
+for r in rows[:16]:
+    print(f'{r["Name"][:64]:64s} {r["Calls"]:>6s} {float(r["AverageNs"]) / 1e3:9.1f} us {r["Percentage"]:>6s}%')
+PY
