@@ -187,15 +187,21 @@ __global__ __launch_bounds__(AT, 2) void attention_f16x3_kernel(const AttnF16Arg
                 half_swap(a1, b1);
                 w[e] = a0; w[4 + e] = b0; w[8 + e] = a1; w[12 + e] = b1;
             }
-            if (q < Lq) {
-                const f32x8 g0 = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
-                const f32x8 g1 = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]};
-                f16x8 hi0, lo0, hi1, lo1;
-                split8(g0, hi0, lo0);
-                split8(g1, hi1, lo1);
-                f16x8* orow = reinterpret_cast<f16x8*>(p.out) + (qbase + q) * (p.ldo >> 2) + ((head * 64 + dt * 32 + 16 * h) >> 2);
-                orow[0] = hi0; orow[1] = lo0; orow[2] = hi1; orow[3] = lo1;
-            }
+            const f32x8 g0 = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
+            const f32x8 g1 = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]};
+            f16x8 hi0, lo0, hi1, lo1;
+            split8(g0, hi0, lo0);
+            split8(g1, hi1, lo1);
+            // quad transpose (common.h): store s writes query s of every quad with 4 lanes x 16 bytes -> full lines
+            u32x4 p0 = __builtin_bit_cast(u32x4, hi0), p1 = __builtin_bit_cast(u32x4, lo0);
+            u32x4 p2 = __builtin_bit_cast(u32x4, hi1), p3 = __builtin_bit_cast(u32x4, lo1);
+            const int ql = i32 & 3;
+            quad_transpose(p0, p1, p2, p3, ql);
+            const int qq = q - ql;  // first query of the quad
+            u32x4* ob = reinterpret_cast<u32x4*>(p.out) + ((head * 64 + dt * 32 + 16 * h) >> 2) + ql;
+#pragma unroll
+            for (int sidx = 0; sidx < 4; ++sidx)
+                if (qq + sidx < Lq) ob[(qbase + qq + sidx) * (p.ldo >> 2)] = sidx == 0 ? p0 : sidx == 1 ? p1 : sidx == 2 ? p2 : p3;
         }
     }
 }

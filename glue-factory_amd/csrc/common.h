@@ -83,6 +83,43 @@ __device__ __forceinline__ float dpp_quad_xor1(float v) {
 __device__ __forceinline__ float dpp_quad_xor2(float v) {
     return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), 0x4E, 0xF, 0xF, false));
 }
+// 4x4 transpose of 16-byte pieces across the four lanes of a quad: afterwards piece s of quad-lane l holds what
+// was piece l of quad-lane s.  Used by the epilogues: a lane owns 64 contiguous output bytes (4 pieces) of one
+// token / pixel, and storing them directly makes every store instruction touch 64 partial lines (measured
+// 3.0 TB/s, tests/micro/bw_pattern.hip); after the transpose instruction s writes row s of every quad with 4 lanes
+// x 16 B, lanes L and L+32 complete the 128-byte line, and the stores run at the coalesced rate (6.5 TB/s).
+__device__ __forceinline__ unsigned dpp_quad_xor1_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);
+}
+__device__ __forceinline__ unsigned dpp_quad_xor2_u(unsigned v) {
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);
+}
+__device__ __forceinline__ void quad_transpose(u32x4& p0, u32x4& p1, u32x4& p2, u32x4& p3, int lane) {
+    const bool odd = lane & 1, hi = lane & 2;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned r = dpp_quad_xor1_u(odd ? p0[e] : p1[e]);
+        p0[e] = odd ? r : p0[e];
+        p1[e] = odd ? p1[e] : r;
+        r = dpp_quad_xor1_u(odd ? p2[e] : p3[e]);
+        p2[e] = odd ? r : p2[e];
+        p3[e] = odd ? p3[e] : r;
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        unsigned r = dpp_quad_xor2_u(hi ? p0[e] : p2[e]);
+        p0[e] = hi ? r : p0[e];
+        p2[e] = hi ? p2[e] : r;
+        r = dpp_quad_xor2_u(hi ? p1[e] : p3[e]);
+        p1[e] = hi ? r : p1[e];
+        p3[e] = hi ? p3[e] : r;
+    }
+}
+// piece q of (p0..p3) for quad-lane q (all four lanes hold the same data, e.g. after a 2x2 max-pool)
+__device__ __forceinline__ u32x4 quad_pick(const u32x4& p0, const u32x4& p1, const u32x4& p2, const u32x4& p3, int lane) {
+    const u32x4 a = (lane & 1) ? p1 : p0, b = (lane & 1) ? p3 : p2;
+    return (lane & 2) ? b : a;
+}
 // Exchange: lanes 32-63 of a <-> lanes 0-31 of b (v_permlane32_swap).  Inline asm on purpose: with
 // ROCm 7.2's hipcc the second result of __builtin_amdgcn_permlane32_swap is lowered to the first one
 // (tests/micro/swap_test.hip shows it).  The two v_nop cover the VALU-write -> permlane-read hazard.

@@ -128,7 +128,7 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
 
     // ---- epilogue ---------------------------------------------------------------------------------
     const int Ho = p.pool ? p.H / 2 : p.H, Wo = p.pool ? p.W / 2 : p.W;
-    const int dy = (i32 >> 1) & 1, dx = i32 & 1, blk = i32 >> 2;
+    const int blk = i32 >> 2;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         // register r of this lane is output channel cb + 8*(r>>2) + 4*h + (r&3)
@@ -165,32 +165,40 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
             // now (lower | upper half): v[0..3],v[8..11] = channels +0..7 | +16..23 ; v[4..7],v[12..15] = +8..15 | +24..31
             const f32x8 g0 = {v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]};
             const f32x8 g1 = {v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]};
-            int oy, ox;
-            bool ok;
-            if (p.pool) {
-                oy = (y0 + wy0 + 2 * nt) >> 1;
-                ox = ((x0 + wx0) >> 1) + blk;
-                ok = ((i32 & 3) == 0) && oy < Ho && ox < Wo;
+            // 64 output bytes of this lane as four 16-byte pieces (SH8: hi|lo|hi|lo, fp32: 4 x float4)
+            u32x4 q0, q1, q2, q3;
+            if (p.out_f32) {
+                q0 = __builtin_bit_cast(u32x4, f32x4{g0[0], g0[1], g0[2], g0[3]});
+                q1 = __builtin_bit_cast(u32x4, f32x4{g0[4], g0[5], g0[6], g0[7]});
+                q2 = __builtin_bit_cast(u32x4, f32x4{g1[0], g1[1], g1[2], g1[3]});
+                q3 = __builtin_bit_cast(u32x4, f32x4{g1[4], g1[5], g1[6], g1[7]});
             } else {
-                oy = y0 + wy0 + 2 * nt + dy;
-                ox = x0 + wx0 + 2 * blk + dx;
-                ok = oy < Ho && ox < Wo;
+                f16x8 hi0, lo0, hi1, lo1;
+                split8(g0, hi0, lo0);
+                split8(g1, hi1, lo1);
+                q0 = __builtin_bit_cast(u32x4, hi0); q1 = __builtin_bit_cast(u32x4, lo0);
+                q2 = __builtin_bit_cast(u32x4, hi1); q3 = __builtin_bit_cast(u32x4, lo1);
             }
             const int ch0 = cb + 16 * h;
-            if (ok && ch0 < p.Cout) {
-                const long long pix = ((long long)b * Ho + oy) * Wo + ox;
-                if (p.out_f32) {
-                    float* o = reinterpret_cast<float*>(p.out) + pix * p.Cout + ch0;
-                    *reinterpret_cast<f32x4*>(o) = f32x4{g0[0], g0[1], g0[2], g0[3]};
-                    *reinterpret_cast<f32x4*>(o + 4) = f32x4{g0[4], g0[5], g0[6], g0[7]};
-                    *reinterpret_cast<f32x4*>(o + 8) = f32x4{g1[0], g1[1], g1[2], g1[3]};
-                    *reinterpret_cast<f32x4*>(o + 12) = f32x4{g1[4], g1[5], g1[6], g1[7]};
-                } else {
-                    f16x8 hi0, lo0, hi1, lo1;
-                    split8(g0, hi0, lo0);
-                    split8(g1, hi1, lo1);
-                    f16x8* o = reinterpret_cast<f16x8*>(p.out) + (pix * p.Cout + ch0) / 4;
-                    o[0] = hi0; o[1] = lo0; o[2] = hi1; o[3] = lo1;
+            const int ql = i32 & 3;  // lane within its 2x2 pixel quad
+            u32x4* obase = reinterpret_cast<u32x4*>(p.out);
+            if (p.pool) {
+                // the four lanes of a quad hold the same pooled values: each writes one 16-byte piece
+                const int oy = (y0 + wy0 + 2 * nt) >> 1, ox = ((x0 + wx0) >> 1) + blk;
+                if (oy < Ho && ox < Wo && ch0 < p.Cout) {
+                    const long long pix = ((long long)b * Ho + oy) * Wo + ox;
+                    obase[(pix * p.Cout + ch0) / 4 + ql] = quad_pick(q0, q1, q2, q3, ql);
+                }
+            } else {
+                // quad transpose: store s writes pixel s of every quad, 4 lanes x 16 bytes
+                quad_transpose(q0, q1, q2, q3, ql);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int oy = y0 + wy0 + 2 * nt + (sidx >> 1), ox = x0 + wx0 + 2 * blk + (sidx & 1);
+                    if (oy < Ho && ox < Wo && ch0 < p.Cout) {
+                        const long long pix = ((long long)b * Ho + oy) * Wo + ox;
+                        obase[(pix * p.Cout + ch0) / 4 + ql] = sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3;
+                    }
                 }
             }
         }
@@ -410,15 +418,17 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
             const f32x8 g1 = {v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]};
             const int oy = (y0 + wy0 + 2 * nt) >> 1;
             const int ox = ((x0 + wx0) >> 1) + blk;
-            const bool ok = ((i32 & 3) == 0) && oy < Ho && ox < Wo;
             const int ch0 = cb + 16 * h;
-            if (ok && ch0 < p.Cout) {
+            if (oy < Ho && ox < Wo && ch0 < p.Cout) {
+                // the four lanes of a quad hold the same pooled values: each writes one 16-byte piece
                 const long long pix = ((long long)b * Ho + oy) * Wo + ox;
                 f16x8 hi0, lo0, hi1, lo1;
                 split8(g0, hi0, lo0);
                 split8(g1, hi1, lo1);
-                f16x8* o = reinterpret_cast<f16x8*>(p.out) + (pix * p.Cout + ch0) / 4;
-                o[0] = hi0; o[1] = lo0; o[2] = hi1; o[3] = lo1;
+                const int ql = i32 & 3;
+                reinterpret_cast<u32x4*>(p.out)[(pix * p.Cout + ch0) / 4 + ql] =
+                    quad_pick(__builtin_bit_cast(u32x4, hi0), __builtin_bit_cast(u32x4, lo0), __builtin_bit_cast(u32x4, hi1),
+                              __builtin_bit_cast(u32x4, lo1), ql);
             }
         }
     }

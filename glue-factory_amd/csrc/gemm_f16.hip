@@ -239,33 +239,49 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
 #pragma unroll
                     for (int j = 0; j < 16; ++j) w[j] *= p.scale;
                 }
-                if (tok_ok && !(p.debug & 1)) {
-                    if (p.residual) {
-                        const float* rs = p.residual + tokc * p.ldr + fb;
+                if (p.residual && tok_ok) {
+                    const float* rs = p.residual + tokc * p.ldr + fb;
 #pragma unroll
-                        for (int j = 0; j < 16; j += 4) {
-                            const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + j);
-                            w[j] += rv.x; w[j + 1] += rv.y; w[j + 2] += rv.z; w[j + 3] += rv.w;
-                        }
+                    for (int j = 0; j < 16; j += 4) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + j);
+                        w[j] += rv.x; w[j + 1] += rv.y; w[j + 2] += rv.z; w[j + 3] += rv.w;
                     }
-                    if (C) {
-                        float* o = C + tokc * p.ldc + fb;
-                        if ((p.ldc & 3) == 0) {
+                }
+                // Stores: the lane's 64 contiguous bytes go out as four 16-byte pieces.  A quad transpose first
+                // (common.h) makes store s write token s of every quad with 4 lanes x 16 B, and lanes L / L+32
+                // complete the 128-byte line: full-line writes instead of 64 partial lines per instruction.
+                const int ql = i32 & 3;
+                const int tq = m0 + wt * 64 + tt * 32 + (i32 & ~3);  // first token of this lane's quad
+                if (C && (p.ldc & 3) == 0) {
+                    u32x4 q0 = __builtin_bit_cast(u32x4, f32x4{w[0], w[1], w[2], w[3]}), q1 = __builtin_bit_cast(u32x4, f32x4{w[4], w[5], w[6], w[7]});
+                    u32x4 q2 = __builtin_bit_cast(u32x4, f32x4{w[8], w[9], w[10], w[11]}), q3 = __builtin_bit_cast(u32x4, f32x4{w[12], w[13], w[14], w[15]});
+                    quad_transpose(q0, q1, q2, q3, ql);
+                    if (!(p.debug & 1)) {
 #pragma unroll
-                            for (int j = 0; j < 16; j += 4) *reinterpret_cast<f32x4*>(o + j) = f32x4{w[j], w[j + 1], w[j + 2], w[j + 3]};
-                        } else {
-#pragma unroll
-                            for (int j = 0; j < 16; ++j) o[j] = w[j];
-                        }
+                        for (int sidx = 0; sidx < 4; ++sidx)
+                            if (tq + sidx < p.M)
+                                *reinterpret_cast<u32x4*>(C + (long long)(tq + sidx) * p.ldc + fb + 4 * ql) = sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3;
                     }
-                    if (p.Cs) {
-                        const f32x8 g0 = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
-                        const f32x8 g1 = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]};
-                        f16x8 hi0, lo0, hi1, lo1;
-                        split8(g0, hi0, lo0);
-                        split8(g1, hi1, lo1);
-                        f16x8* o = reinterpret_cast<f16x8*>(p.Cs) + ((tokc * p.ldcs + fb) >> 2) + z * (p.strideCs >> 2);
-                        o[0] = hi0; o[1] = lo0; o[2] = hi1; o[3] = lo1;
+                } else if (C && tok_ok && !(p.debug & 1)) {
+                    float* o = C + tokc * p.ldc + fb;
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) o[j] = w[j];
+                }
+                if (p.Cs) {
+                    const f32x8 g0 = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
+                    const f32x8 g1 = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]};
+                    f16x8 hi0, lo0, hi1, lo1;
+                    split8(g0, hi0, lo0);
+                    split8(g1, hi1, lo1);
+                    u32x4 q0 = __builtin_bit_cast(u32x4, hi0), q1 = __builtin_bit_cast(u32x4, lo0);
+                    u32x4 q2 = __builtin_bit_cast(u32x4, hi1), q3 = __builtin_bit_cast(u32x4, lo1);
+                    quad_transpose(q0, q1, q2, q3, ql);
+                    u32x4* ob = reinterpret_cast<u32x4*>(p.Cs) + z * (p.strideCs >> 2);
+                    if (!(p.debug & 1)) {
+#pragma unroll
+                        for (int sidx = 0; sidx < 4; ++sidx)
+                            if (tq + sidx < p.M)
+                                ob[(((long long)(tq + sidx) * p.ldcs + fb) >> 2) + ql] = sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3;
                     }
                 }
             } else {

@@ -49,6 +49,45 @@ __global__ __launch_bounds__(256) void write_tiled(u32x4* out, int row_u4, int c
     }
 }
 
+// every store instruction of a wave covers 1 KB contiguous
+__global__ __launch_bounds__(256) void write_coalesced(u32x4* out, int row_u4, int chunks) {
+    const int t = threadIdx.x;
+    const long long base = (long long)blockIdx.x * 256 * row_u4;
+    for (int c = 0; c < chunks; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[base + (long long)c * 1024 + q * 256 + t] = u32x4{(unsigned)t, (unsigned)c, (unsigned)q, 1u};
+    }
+}
+// same, 4-byte stores (what a plain fp32 epilogue does)
+__global__ __launch_bounds__(256) void write_coalesced_b32(unsigned* out, int row_u4, int chunks) {
+    const int t = threadIdx.x;
+    const long long base = (long long)blockIdx.x * 256 * row_u4 * 4;
+    for (int c = 0; c < chunks * 16; ++c) out[base + (long long)c * 256 + t] = (unsigned)(t + c);
+}
+__global__ __launch_bounds__(256) void copy_coalesced(const u32x4* in, u32x4* out, int row_u4, int chunks) {
+    const int t = threadIdx.x;
+    const long long base = (long long)blockIdx.x * 256 * row_u4;
+    for (int c = 0; c < chunks; ++c) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[base + (long long)c * 1024 + q * 256 + t] = in[base + (long long)c * 1024 + q * 256 + t];
+    }
+}
+
+// proposed epilogue: after a quad transpose, 4 lanes write one row's 64 B and lanes L / L+32 the two halves of a
+// 128-byte line: every store instruction writes 8 full lines (row stride 1 KB)
+__global__ __launch_bounds__(256) void write_quad(u32x4* out, int row_u4, int chunks) {
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int h = lane >> 5, j = (lane & 31) >> 2, q = lane & 3;
+    const long long row0 = (long long)blockIdx.x * 256 + wave * 64;
+    for (int c = 0; c < chunks / 2; ++c)       // 128-byte column chunks
+        for (int half = 0; half < 2; ++half)   // two 32-row MFMA tiles per wave
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const long long row = row0 + half * 32 + 4 * j + s;
+                out[row * row_u4 + c * 8 + h * 4 + q] = u32x4{(unsigned)t, (unsigned)c, (unsigned)s, 1u};
+            }
+}
+
 int main() {
     const int rows = 65536 * 2, row_u4 = 64;  // 128 K rows x 1 KB = 134 MB
     const size_t bytes = (size_t)rows * row_u4 * 16;
@@ -71,6 +110,11 @@ int main() {
     time("read tiled", [&] { hipLaunchKernelGGL(read_tiled, dim3(grid), dim3(256), 0, 0, (flip ^= 1) ? a : b, o, row_u4, 16); });
     time("write strided", [&] { hipLaunchKernelGGL(write_strided, dim3(grid), dim3(256), 0, 0, (flip ^= 1) ? a : b, row_u4, 16); });
     time("write tiled", [&] { hipLaunchKernelGGL(write_tiled, dim3(grid), dim3(256), 0, 0, (flip ^= 1) ? a : b, row_u4, 16); });
+    time("write quad", [&] { hipLaunchKernelGGL(write_quad, dim3(grid), dim3(256), 0, 0, (flip ^= 1) ? a : b, row_u4, 16); });
+    time("write coalesced", [&] { hipLaunchKernelGGL(write_coalesced, dim3(grid), dim3(256), 0, 0, (flip ^= 1) ? a : b, row_u4, 16); });
+    time("write coal. b32", [&] { hipLaunchKernelGGL(write_coalesced_b32, dim3(grid), dim3(256), 0, 0, (unsigned*)((flip ^= 1) ? a : b), row_u4, 16); });
+    time("hipMemsetAsync", [&] { hipMemsetAsync((flip ^= 1) ? a : b, 3, bytes, 0); });
+    time("copy (r+w bytes/2)", [&] { hipLaunchKernelGGL(copy_coalesced, dim3(grid), dim3(256), 0, 0, a, b, row_u4, 16); });
     hipError_t e = hipDeviceSynchronize();
     printf("status %s\n", hipGetErrorString(e));
     return e != hipSuccess;
