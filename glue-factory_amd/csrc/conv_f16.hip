@@ -20,6 +20,20 @@ namespace {
 
 constexpr int CT = 512;  // threads per workgroup of the 8-wave arrangements
 
+// Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Re-number them so that one XCD works
+// through a CONTIGUOUS run of (image, tile, cout slice) items with the slice index fastest: the cout slices of a
+// pixel tile (which read the same input tile) and spatially adjacent tiles (which share halo rows / columns) are
+// then in flight on the same L2 at the same time instead of being fetched from HBM once per XCD.
+__device__ __forceinline__ void xcd_item(int tiles, int nslices, int& tile, int& slice, int& b) {
+    const int total = gridDim.x, id = blockIdx.x;
+    int logical = id;
+    if ((total & 7) == 0) logical = (id & 7) * (total >> 3) + (id >> 3);
+    slice = logical % nslices;
+    const int r = logical / nslices;
+    tile = r % tiles;
+    b = r / tiles;
+}
+
 template <int WY, int WX, int KYU>
 __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const ConvF16Args p) {
     constexpr int CT = 64 * WY * WX;
@@ -32,10 +46,11 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
     __shared__ u32x4 s_w[9 * 64 * 4];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int tiles_x = (p.W + TW - 1) / TW;
-    const int y0 = (blockIdx.x / tiles_x) * TH, x0 = (blockIdx.x % tiles_x) * TW;
-    const int n0 = blockIdx.y * 64;
-    const int b = blockIdx.z;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    int tile, slice, b;
+    xcd_item(tiles_x * tiles_y, (p.Cout + 63) / 64, tile, slice, b);
+    const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
+    const int n0 = slice * 64;
     const int cin4 = p.Cin >> 2;  // u32x4 per pixel
     const u32x4* in = reinterpret_cast<const u32x4*>(p.in) + (long long)b * p.H * p.W * cin4;
     const u32x4* wt = reinterpret_cast<const u32x4*>(p.Wt);
@@ -54,21 +69,26 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
         in_loff[i] = in_tile ? (P * 4 + (q ^ ((P >> 2) & 3))) : -1;
     }
 
-    u32x4 rin[NIN], rwt[NWT];
+    // Staging registers: the input tile comes from HBM and is prefetched TWO chunks ahead (two register sets,
+    // used alternately), the weight slice comes from L2 and runs one chunk ahead; vmcnt retires in order, so
+    // the weights of chunk c+1 are requested before the inputs of chunk c+2.
+    u32x4 rinA[NIN], rinB[NIN], rwt[NWT];
     const int nchunks = p.Cin >> 4;
-    auto load_chunk = [&](int c) {
+    auto load_in = [&](u32x4 (&r)[NIN], int c) {
 #pragma unroll
-        for (int i = 0; i < NIN; ++i) rin[i] = (in_goff[i] >= 0) ? in[in_goff[i] + c * 4] : u32x4{0u, 0u, 0u, 0u};
+        for (int i = 0; i < NIN; ++i) r[i] = (in_goff[i] >= 0) ? in[in_goff[i] + c * 4] : u32x4{0u, 0u, 0u, 0u};
+    };
+    auto load_w = [&](int c) {
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int idx = t + CT * i, row = idx >> 2, q = idx & 3, tap = row >> 6, n = row & 63;
             rwt[i] = (idx < 9 * 64 * 4) ? wt[((long long)(c * 9 + tap) * p.CoutPad + n0 + n) * 4 + q] : u32x4{0u, 0u, 0u, 0u};
         }
     };
-    auto store_chunk = [&]() {
+    auto store_chunk = [&](const u32x4 (&r)[NIN]) {
 #pragma unroll
         for (int i = 0; i < NIN; ++i)
-            if (in_loff[i] >= 0) s_in[in_loff[i]] = rin[i];
+            if (in_loff[i] >= 0) s_in[in_loff[i]] = r[i];
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int idx = t + CT * i, row = idx >> 2, q = idx & 3;
@@ -92,12 +112,7 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
     const int wsw = (i32 >> 2) & 3;
     const int a_hi = i32 * 4 + ((2 * h) ^ wsw), a_lo = i32 * 4 + ((2 * h + 1) ^ wsw);
 
-    load_chunk(0);
-    for (int c = 0; c < nchunks; ++c) {
-        __syncthreads();  // everyone is done reading the previous chunk
-        store_chunk();
-        __syncthreads();
-        if (c + 1 < nchunks) load_chunk(c + 1);
+    auto multiply = [&]() {
         const f16x8* si = reinterpret_cast<const f16x8*>(s_in);
         const f16x8* sw = reinterpret_cast<const f16x8*>(s_w);
 #pragma unroll KYU
@@ -123,6 +138,27 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) mma3(ah[mt], al[mt], bh[nt], bl[nt], acc[mt][nt]);
             }
+        }
+    };
+
+    load_in(rinA, 0);
+    load_w(0);
+    if (nchunks > 1) load_in(rinB, 1);
+#pragma unroll 1
+    for (int c = 0; c < nchunks; c += 2) {  // Cin is a multiple of 32 for every layer on this path (64 / 128)
+        __syncthreads();  // everyone is done reading the previous chunk
+        store_chunk(rinA);
+        __syncthreads();
+        if (c + 1 < nchunks) load_w(c + 1);
+        if (c + 2 < nchunks) load_in(rinA, c + 2);
+        multiply();
+        if (c + 1 < nchunks) {
+            __syncthreads();
+            store_chunk(rinB);
+            __syncthreads();
+            if (c + 2 < nchunks) load_w(c + 2);
+            if (c + 3 < nchunks) load_in(rinB, c + 3);
+            multiply();
         }
     }
 
@@ -225,10 +261,11 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wave);
-    const int tiles_x = (p.W + TW - 1) / TW;
-    const int y0 = (blockIdx.x / tiles_x) * TH, x0 = (blockIdx.x % tiles_x) * TW;
-    const int n0 = blockIdx.y * 64;
-    const int b = blockIdx.z;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    int tile, slice, b;
+    xcd_item(tiles_x * tiles_y, (p.Cout + 63) / 64, tile, slice, b);
+    const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
+    const int n0 = slice * 64;
     const u32x4* wt = reinterpret_cast<const u32x4*>(p.Wt);
 
     // gray tile (RGB -> gray as superpoint.py:204-206), zero outside the image
@@ -346,19 +383,32 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
                 for (int nt = 0; nt < 2; ++nt) {
                     const int P = P0 + (2 * nt + ky) * PW + kx;
                     const int sw4 = (P >> 2) & 3;
+#if defined(CONV_ABL) && (CONV_ABL == 1 || CONV_ABL == 2)  // timing experiment: half the pixel-operand reads
+                    if (nt == 1) { bh[1] = bh[0]; bl[1] = bl[0]; continue; }
+#endif
                     bh[nt] = si[P * 4 + ((2 * h) ^ sw4)];
                     bl[nt] = si[P * 4 + ((2 * h + 1) ^ sw4)];
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt) {
                     const int ro = ((ky * 3 + kx) * 64 + mt * 32) * 4;
+#if defined(CONV_ABL) && CONV_ABL == 2  // timing experiment: half the weight-operand reads too
+                    if (mt == 1) { ah[1] = ah[0]; al[1] = al[0]; continue; }
+#endif
                     ah[mt] = sw[ro + a_hi];
                     al[mt] = sw[ro + a_lo];
                 }
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) mma3(ah[mt], al[mt], bh[nt], bl[nt], acc[mt][nt]);
+                    for (int nt = 0; nt < 2; ++nt) {
+#if defined(CONV_ABL) && CONV_ABL == 3  // timing experiment: one MFMA product instead of three
+                        acc[mt][nt] = mfma16(ah[mt], bh[nt], acc[mt][nt]);
+                        (void)al; (void)bl;
+#else
+                        mma3(ah[mt], al[mt], bh[nt], bl[nt], acc[mt][nt]);
+#endif
+                    }
             }
         }
     };
@@ -502,19 +552,19 @@ void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
     // than one 8-wave workgroup per CU on the 240x320 and 120x160 maps.
     const long long w22 = waste(8, 32);
     if (w22 <= w42 && w22 <= w81) {
-        dim3 grid(((a.H + 7) / 8) * ((a.W + 31) / 32), nslices, a.B);
+        dim3 grid(((a.H + 7) / 8) * ((a.W + 31) / 32) * nslices * a.B);
         hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, 2, 1>), grid, dim3(256), 0, s, a);
     } else if (w42 <= w81) {
-        dim3 grid(((a.H + 15) / 16) * ((a.W + 31) / 32), nslices, a.B);
+        dim3 grid(((a.H + 15) / 16) * ((a.W + 31) / 32) * nslices * a.B);
         hipLaunchKernelGGL((conv3x3_f16x3_kernel<4, 2, 3>), grid, dim3(CT), 0, s, a);
     } else {
-        dim3 grid(((a.H + 31) / 32) * ((a.W + 15) / 16), nslices, a.B);
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<8, 1, 3>), grid, dim3(CT), 0, s, a);
+        dim3 grid(((a.H + 31) / 32) * ((a.W + 15) / 16) * nslices * a.B);
+        hipLaunchKernelGGL((conv3x3_f16x3_kernel<8, 1, 1>), grid, dim3(CT), 0, s, a);
     }
 }
 
 void launch_conv1ab_f16x3(const ConvF16Args& a, const Conv1aArgs& c1, hipStream_t s) {
-    dim3 grid(((a.H + 15) / 16) * ((a.W + 31) / 32), (a.Cout + 63) / 64, a.B);
+    dim3 grid(((a.H + 15) / 16) * ((a.W + 31) / 32) * ((a.Cout + 63) / 64) * a.B);
     hipLaunchKernelGGL(conv1ab_f16x3_kernel, grid, dim3(CT), 0, s, a, c1);
 }
 
