@@ -34,6 +34,88 @@ __device__ __forceinline__ void xcd_item(int tiles, int nslices, int& tile, int&
     b = r / tiles;
 }
 
+
+// (v[i], v[i+8]) half-wave exchanges of one accumulator tile in one asm block (one hazard gap instead of eight)
+__device__ __forceinline__ void half_swap8(float (&v)[16]) {
+    asm volatile(
+        "v_nop\n\tv_nop\n\t"
+        "v_permlane32_swap_b32 %0, %8\n\tv_permlane32_swap_b32 %1, %9\n\t"
+        "v_permlane32_swap_b32 %2, %10\n\tv_permlane32_swap_b32 %3, %11\n\t"
+        "v_permlane32_swap_b32 %4, %12\n\tv_permlane32_swap_b32 %5, %13\n\t"
+        "v_permlane32_swap_b32 %6, %14\n\tv_permlane32_swap_b32 %7, %15"
+        : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]), "+v"(v[8]), "+v"(v[9]),
+          "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
+}
+
+#if defined(CONV_ABL) && CONV_ABL == 8
+#define STORE_OUT(ptr, val) __builtin_nontemporal_store((val), (ptr))
+#else
+#define STORE_OUT(ptr, val) (*(ptr) = (val))
+#endif
+// Hot epilogue (every layer of the MagicLeap layout): ReLU on accumulators that were initialised with the bias,
+// optional 2x2 max-pool inside the lane quad, SH8 output.  32-bit offsets inside the image, no per-channel loads.
+template <bool POOL>
+__device__ __forceinline__ void epilogue_sh8(f32x16 (&acc)[2][2], u32x4* __restrict__ out_img, int H, int W, int Cout, int yw, int xw, int n0,
+                                             int lane) {
+    const int i32 = lane & 31, h = lane >> 5, ql = i32 & 3, blk = i32 >> 2;
+    const int c4 = Cout >> 2;
+#if defined(CONV_ABL) && CONV_ABL == 7  // timing experiment 7: the whole epilogue runs but no store is executed
+    const int Ho = Cout > 100000 ? 1 : 0, Wo = POOL ? W >> 1 : W;
+#else
+    const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+#endif
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int ch0 = n0 + mt * 32 + 16 * h;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = fmaxf(acc[mt][nt][r], 0.f);
+                if (POOL) {
+                    x = fmaxf(x, dpp_quad_xor1(x));
+                    x = fmaxf(x, dpp_quad_xor2(x));
+                }
+                v[r] = x;
+            }
+            half_swap8(v);
+            // (lower | upper half-wave): v[0..3],v[8..11] = channels +0..7 | +16..23 ; v[4..7],v[12..15] = +8..15 | +24..31
+            f16x8 hi0, lo0, hi1, lo1;
+            split8(f32x8{v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]}, hi0, lo0);
+            split8(f32x8{v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]}, hi1, lo1);
+            u32x4 q0 = __builtin_bit_cast(u32x4, hi0), q1 = __builtin_bit_cast(u32x4, lo0);
+            u32x4 q2 = __builtin_bit_cast(u32x4, hi1), q3 = __builtin_bit_cast(u32x4, lo1);
+            if (POOL) {
+                const int oy = (yw >> 1) + nt, ox = (xw >> 1) + blk;
+                if (oy < Ho && ox < Wo && ch0 < Cout) STORE_OUT(&out_img[(oy * Wo + ox) * c4 + (ch0 >> 2) + ql], quad_pick(q0, q1, q2, q3, ql));
+            } else {
+                quad_transpose(q0, q1, q2, q3, ql);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int oy = yw + 2 * nt + (sidx >> 1), ox = xw + 2 * blk + (sidx & 1);
+                    if (oy < Ho && ox < Wo && ch0 < Cout)
+                        STORE_OUT(&out_img[(oy * Wo + ox) * c4 + (ch0 >> 2) + ql], sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3);
+                }
+            }
+        }
+    }
+}
+
+// accumulators start at the bias of their output channel (register r of a lane: channel cb + 8*(r>>2) + 4*h + (r&3))
+__device__ __forceinline__ void init_acc_bias(f32x16 (&acc)[2][2], const float* __restrict__ bias, int n0, int Cout, int h) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int ch = n0 + mt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
+            const float bl = bias[min(ch, Cout - 1)];  // clamped load + select: no exec-mask branch per register
+            const float bv = ch < Cout ? bl : 0.f;
+            acc[mt][0][r] = bv;
+            acc[mt][1][r] = bv;
+        }
+}
+
 template <int WY, int WX, int KYU>
 __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const ConvF16Args p) {
     constexpr int CT = 64 * WY * WX;
@@ -96,16 +178,10 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
         }
     };
 
-    f32x16 acc[2][2];  // [cout tile][pixel tile]
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int wy0 = (wave / WX) * 4, wx0 = (wave % WX) * 16;
     const int i32 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];  // [cout tile][pixel tile]
+    init_acc_bias(acc, p.bias, n0, p.Cout, h);
     // pixel operand: lane n -> pixel (dy,dx) = ((n>>1)&1, n&1) of 2x2 block n>>2 (blocks along x)
     const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
     // weight operand: row = tap*64 + mt*32 + i32; swizzle term depends on i32 only
@@ -149,32 +225,49 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
         __syncthreads();  // everyone is done reading the previous chunk
         store_chunk(rinA);
         __syncthreads();
+#if !(defined(CONV_ABL) && CONV_ABL == 6)  // timing experiment 6: no global loads after the first two chunks
         if (c + 1 < nchunks) load_w(c + 1);
         if (c + 2 < nchunks) load_in(rinA, c + 2);
+#endif
         multiply();
         if (c + 1 < nchunks) {
             __syncthreads();
             store_chunk(rinB);
             __syncthreads();
+#if !(defined(CONV_ABL) && CONV_ABL == 6)
             if (c + 2 < nchunks) load_w(c + 2);
             if (c + 3 < nchunks) load_in(rinB, c + 3);
+#endif
             multiply();
         }
     }
+#if defined(CONV_ABL) && CONV_ABL == 5  // timing experiment 5: no epilogue (the impossible compare keeps the MFMAs alive)
+    if (acc[0][0][0] != 12345.678f || acc[1][1][5] != 1.25f || acc[0][1][3] != 7.f || acc[1][0][9] != 3.f) return;
+#endif
 
     // ---- epilogue ---------------------------------------------------------------------------------
+    if (p.relu && !p.out_f32 && !p.post_scale) {
+        if (p.pool) {
+            u32x4* oimg = reinterpret_cast<u32x4*>(p.out) + (long long)b * (p.H >> 1) * (p.W >> 1) * (p.Cout >> 2);
+            epilogue_sh8<true>(acc, oimg, p.H, p.W, p.Cout, y0 + wy0, x0 + wx0, n0, lane);
+        } else {
+            u32x4* oimg = reinterpret_cast<u32x4*>(p.out) + (long long)b * p.H * p.W * (p.Cout >> 2);
+            epilogue_sh8<false>(acc, oimg, p.H, p.W, p.Cout, y0 + wy0, x0 + wx0, n0, lane);
+        }
+        return;
+    }
+    // generic path: BatchNorm affine after the ReLU (open variant), fp32 output, linear layers
     const int Ho = p.pool ? p.H / 2 : p.H, Wo = p.pool ? p.W / 2 : p.W;
     const int blk = i32 >> 2;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         // register r of this lane is output channel cb + 8*(r>>2) + 4*h + (r&3)
         const int cb = n0 + mt * 32;
-        float bias[16], ps[16], pt[16];
+        float ps[16], pt[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ch = cb + 8 * (r >> 2) + 4 * h + (r & 3);
             const bool ok = ch < p.Cout;
-            bias[r] = ok ? p.bias[ch] : 0.f;
             ps[r] = (p.post_scale && ok) ? p.post_scale[ch] : 1.f;
             pt[r] = (p.post_shift && ok) ? p.post_shift[ch] : 0.f;
         }
@@ -183,7 +276,7 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float x = acc[mt][nt][r] + bias[r];
+                float x = acc[mt][nt][r];  // bias is already in the accumulator
                 if (p.relu) x = fmaxf(x, 0.f);
                 if (p.post_scale) x = __fadd_rn(__fmul_rn(x, ps[r]), pt[r]);
                 if (p.pool) {
@@ -357,16 +450,10 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
         }
     };
 
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 2; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
     const int wy0 = (wave / WX) * 4, wx0 = (wave % WX) * 16;
     const int i32 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+    init_acc_bias(acc, p.bias, n0, p.Cout, h);
     const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
     const int wsw = (i32 >> 2) & 3;
     const int a_hi = i32 * 4 + ((2 * h) ^ wsw), a_lo = i32 * 4 + ((2 * h + 1) ^ wsw);
@@ -433,17 +520,21 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
     }
 
     // ---- epilogue: identical to conv3x3_f16x3_kernel with pool = 1, SH8 output ----------------------
+    if (!p.post_scale) {
+        u32x4* oimg = reinterpret_cast<u32x4*>(p.out) + (long long)b * (p.H >> 1) * (p.W >> 1) * (p.Cout >> 2);
+        epilogue_sh8<true>(acc, oimg, p.H, p.W, p.Cout, y0 + wy0, x0 + wx0, n0, lane);
+        return;
+    }
     const int Ho = p.H / 2, Wo = p.W / 2;
     const int blk = i32 >> 2;
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
         const int cb = n0 + mt * 32;
-        float bias[16], ps[16], pt[16];
+        float ps[16], pt[16];
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int ch = cb + 8 * (r >> 2) + 4 * h + (r & 3);
             const bool ok = ch < p.Cout;
-            bias[r] = ok ? p.bias[ch] : 0.f;
             ps[r] = (p.post_scale && ok) ? p.post_scale[ch] : 1.f;
             pt[r] = (p.post_shift && ok) ? p.post_shift[ch] : 0.f;
         }
@@ -452,7 +543,7 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float x = acc[mt][nt][r] + bias[r];
+                float x = acc[mt][nt][r];  // bias is already in the accumulator
                 x = fmaxf(x, 0.f);
                 if (p.post_scale) x = __fadd_rn(__fmul_rn(x, ps[r]), pt[r]);
                 x = fmaxf(x, dpp_quad_xor1(x));
