@@ -13,6 +13,8 @@
 //     (SH8 for the next MFMA consumer, or plain fp32 NHWC).
 // A workgroup is 8 waves (16x32 or 32x16 pixels x 64 channels), one per CU with two waves per SIMD:
 // one 83 KB LDS stage, the next chunk prefetched into registers while the current one is multiplied.
+#include <algorithm>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -116,143 +118,31 @@ __device__ __forceinline__ void init_acc_bias(f32x16 (&acc)[2][2], const float* 
         }
 }
 
-template <int WY, int WX, int KYU>
-__global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const ConvF16Args p) {
-    constexpr int CT = 64 * WY * WX;
-    constexpr int TH = 4 * WY, TW = 16 * WX;
-    constexpr int PW = ((TW + 2 + 7) / 16) * 16 + 8;  // pixel pitch == 8 (mod 16), >= TW + 2
-    constexpr int NPIX = (TH + 2) * (TW + 2);
-    constexpr int NIN = (NPIX * 4 + CT - 1) / CT;
-    constexpr int NWT = (9 * 64 * 4 + CT - 1) / CT;
-    __shared__ u32x4 s_in[(TH + 2) * PW * 4];
-    __shared__ u32x4 s_w[9 * 64 * 4];
-
-    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
-    int tile, slice, b;
-    xcd_item(tiles_x * tiles_y, (p.Cout + 63) / 64, tile, slice, b);
-    const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
-    const int n0 = slice * 64;
-    const int cin4 = p.Cin >> 2;  // u32x4 per pixel
-    const u32x4* in = reinterpret_cast<const u32x4*>(p.in) + (long long)b * p.H * p.W * cin4;
-    const u32x4* wt = reinterpret_cast<const u32x4*>(p.Wt);
-
-    int in_goff[NIN], in_loff[NIN];
-#pragma unroll
-    for (int i = 0; i < NIN; ++i) {
-        const int idx = t + CT * i;
-        const int pix = idx >> 2, q = idx & 3;
-        const int py = pix / (TW + 2), px = pix - py * (TW + 2);
-        const int gy = y0 + py - 1, gx = x0 + px - 1;
-        const bool in_tile = idx < NPIX * 4;
-        const bool ok = in_tile && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-        const int P = py * PW + px;
-        in_goff[i] = ok ? ((gy * p.W + gx) * cin4 + q) : -1;
-        in_loff[i] = in_tile ? (P * 4 + (q ^ ((P >> 2) & 3))) : -1;
-    }
-
-    // Staging registers: the input tile comes from HBM and is prefetched TWO chunks ahead (two register sets,
-    // used alternately), the weight slice comes from L2 and runs one chunk ahead; vmcnt retires in order, so
-    // the weights of chunk c+1 are requested before the inputs of chunk c+2.
-    u32x4 rinA[NIN], rinB[NIN], rwt[NWT];
-    const int nchunks = p.Cin >> 4;
-    auto load_in = [&](u32x4 (&r)[NIN], int c) {
-#pragma unroll
-        for (int i = 0; i < NIN; ++i) r[i] = (in_goff[i] >= 0) ? in[in_goff[i] + c * 4] : u32x4{0u, 0u, 0u, 0u};
-    };
-    auto load_w = [&](int c) {
-#pragma unroll
-        for (int i = 0; i < NWT; ++i) {
-            const int idx = t + CT * i, row = idx >> 2, q = idx & 3, tap = row >> 6, n = row & 63;
-            rwt[i] = (idx < 9 * 64 * 4) ? wt[((long long)(c * 9 + tap) * p.CoutPad + n0 + n) * 4 + q] : u32x4{0u, 0u, 0u, 0u};
-        }
-    };
-    auto store_chunk = [&](const u32x4 (&r)[NIN]) {
-#pragma unroll
-        for (int i = 0; i < NIN; ++i)
-            if (in_loff[i] >= 0) s_in[in_loff[i]] = r[i];
-#pragma unroll
-        for (int i = 0; i < NWT; ++i) {
-            const int idx = t + CT * i, row = idx >> 2, q = idx & 3;
-            if (idx < 9 * 64 * 4) s_w[row * 4 + (q ^ ((row >> 2) & 3))] = rwt[i];
-        }
-    };
-
-    const int wy0 = (wave / WX) * 4, wx0 = (wave % WX) * 16;
+// Epilogue of one 64-cout x (4 x 16)-pixel wave tile.  `sb` = the 64 biases of this cout slice in LDS (nullptr when
+// the accumulators were initialised with the bias).  Hot path: ReLU + SH8 (+ pool); generic path below it.
+template <bool GENERIC>
+__device__ __forceinline__ void conv_epilogue(const ConvF16Args& p, f32x16 (&acc)[2][2], const float* sb, int b, int yw, int xw, int n0, int lane) {
     const int i32 = lane & 31, h = lane >> 5;
-    f32x16 acc[2][2];  // [cout tile][pixel tile]
-    init_acc_bias(acc, p.bias, n0, p.Cout, h);
-    // pixel operand: lane n -> pixel (dy,dx) = ((n>>1)&1, n&1) of 2x2 block n>>2 (blocks along x)
-    const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
-    // weight operand: row = tap*64 + mt*32 + i32; swizzle term depends on i32 only
-    const int wsw = (i32 >> 2) & 3;
-    const int a_hi = i32 * 4 + ((2 * h) ^ wsw), a_lo = i32 * 4 + ((2 * h + 1) ^ wsw);
-
-    auto multiply = [&]() {
-        const f16x8* si = reinterpret_cast<const f16x8*>(s_in);
-        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w);
-#pragma unroll KYU
-        for (int ky = 0; ky < 3; ++ky) {
+    if (sb) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                f16x8 bh[2], bl[2], ah[2], al[2];
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + mt * 32 + 8 * j + 4 * h);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    const int P = P0 + (2 * nt + ky) * PW + kx;
-                    const int sw4 = (P >> 2) & 3;
-                    bh[nt] = si[P * 4 + ((2 * h) ^ sw4)];
-                    bl[nt] = si[P * 4 + ((2 * h + 1) ^ sw4)];
+                    acc[mt][nt][4 * j] += bv[0]; acc[mt][nt][4 * j + 1] += bv[1];
+                    acc[mt][nt][4 * j + 2] += bv[2]; acc[mt][nt][4 * j + 3] += bv[3];
                 }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int ro = ((ky * 3 + kx) * 64 + mt * 32) * 4;
-                    ah[mt] = sw[ro + a_hi];
-                    al[mt] = sw[ro + a_lo];
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) mma3(ah[mt], al[mt], bh[nt], bl[nt], acc[mt][nt]);
             }
-        }
-    };
-
-    load_in(rinA, 0);
-    load_w(0);
-    if (nchunks > 1) load_in(rinB, 1);
-#pragma unroll 1
-    for (int c = 0; c < nchunks; c += 2) {  // Cin is a multiple of 32 for every layer on this path (64 / 128)
-        __syncthreads();  // everyone is done reading the previous chunk
-        store_chunk(rinA);
-        __syncthreads();
-#if !(defined(CONV_ABL) && CONV_ABL == 6)  // timing experiment 6: no global loads after the first two chunks
-        if (c + 1 < nchunks) load_w(c + 1);
-        if (c + 2 < nchunks) load_in(rinA, c + 2);
-#endif
-        multiply();
-        if (c + 1 < nchunks) {
-            __syncthreads();
-            store_chunk(rinB);
-            __syncthreads();
-#if !(defined(CONV_ABL) && CONV_ABL == 6)
-            if (c + 2 < nchunks) load_w(c + 2);
-            if (c + 3 < nchunks) load_in(rinB, c + 3);
-#endif
-            multiply();
-        }
     }
-#if defined(CONV_ABL) && CONV_ABL == 5  // timing experiment 5: no epilogue (the impossible compare keeps the MFMAs alive)
-    if (acc[0][0][0] != 12345.678f || acc[1][1][5] != 1.25f || acc[0][1][3] != 7.f || acc[1][0][9] != 3.f) return;
-#endif
-
-    // ---- epilogue ---------------------------------------------------------------------------------
-    if (p.relu && !p.out_f32 && !p.post_scale) {
+    if (!GENERIC) {  // the launcher picks this instantiation when relu && !out_f32 && !post_scale
         if (p.pool) {
             u32x4* oimg = reinterpret_cast<u32x4*>(p.out) + (long long)b * (p.H >> 1) * (p.W >> 1) * (p.Cout >> 2);
-            epilogue_sh8<true>(acc, oimg, p.H, p.W, p.Cout, y0 + wy0, x0 + wx0, n0, lane);
+            epilogue_sh8<true>(acc, oimg, p.H, p.W, p.Cout, yw, xw, n0, lane);
         } else {
             u32x4* oimg = reinterpret_cast<u32x4*>(p.out) + (long long)b * p.H * p.W * (p.Cout >> 2);
-            epilogue_sh8<false>(acc, oimg, p.H, p.W, p.Cout, y0 + wy0, x0 + wx0, n0, lane);
+            epilogue_sh8<false>(acc, oimg, p.H, p.W, p.Cout, yw, xw, n0, lane);
         }
         return;
     }
@@ -276,7 +166,7 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
             float v[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                float x = acc[mt][nt][r];  // bias is already in the accumulator
+                float x = acc[mt][nt][r];
                 if (p.relu) x = fmaxf(x, 0.f);
                 if (p.post_scale) x = __fadd_rn(__fmul_rn(x, ps[r]), pt[r]);
                 if (p.pool) {
@@ -313,7 +203,7 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
             u32x4* obase = reinterpret_cast<u32x4*>(p.out);
             if (p.pool) {
                 // the four lanes of a quad hold the same pooled values: each writes one 16-byte piece
-                const int oy = (y0 + wy0 + 2 * nt) >> 1, ox = ((x0 + wx0) >> 1) + blk;
+                const int oy = (yw + 2 * nt) >> 1, ox = ((xw) >> 1) + blk;
                 if (oy < Ho && ox < Wo && ch0 < p.Cout) {
                     const long long pix = ((long long)b * Ho + oy) * Wo + ox;
                     obase[(pix * p.Cout + ch0) / 4 + ql] = quad_pick(q0, q1, q2, q3, ql);
@@ -323,7 +213,7 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
                 quad_transpose(q0, q1, q2, q3, ql);
 #pragma unroll
                 for (int sidx = 0; sidx < 4; ++sidx) {
-                    const int oy = y0 + wy0 + 2 * nt + (sidx >> 1), ox = x0 + wx0 + 2 * blk + (sidx & 1);
+                    const int oy = yw + 2 * nt + (sidx >> 1), ox = xw + 2 * blk + (sidx & 1);
                     if (oy < Ho && ox < Wo && ch0 < p.Cout) {
                         const long long pix = ((long long)b * Ho + oy) * Wo + ox;
                         obase[(pix * p.Cout + ch0) / 4 + ql] = sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3;
@@ -331,6 +221,160 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
                 }
             }
         }
+    }
+}
+
+// Persistent: a workgroup walks a strided list of (image, tile, cout slice) items and treats their 16-channel
+// chunks as ONE stream of stages -- the inputs of stage s+2 and the weights of stage s+1 are requested while stage
+// s is multiplied, across item boundaries.  The epilogue's stores are fire-and-forget: the next item's first two
+// chunks are already in flight, nothing waits for a workgroup to retire (measured: the stores of a one-tile
+// workgroup cost 20-25 % of the kernel, the time its slot sat idle until they were acknowledged).
+template <int WY, int WX, int KYU, bool GENERIC>
+__global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const ConvF16Args p) {
+    constexpr int CT = 64 * WY * WX;
+    constexpr int TH = 4 * WY, TW = 16 * WX;
+    constexpr int PW = ((TW + 2 + 7) / 16) * 16 + 8;  // pixel pitch == 8 (mod 16), >= TW + 2
+    constexpr int NPIX = (TH + 2) * (TW + 2);
+    constexpr int NIN = (NPIX * 4 + CT - 1) / CT;
+    constexpr int NWT = (9 * 64 * 4 + CT - 1) / CT;
+    __shared__ u32x4 s_in[(TH + 2) * PW * 4];
+    __shared__ u32x4 s_w[9 * 64 * 4];
+    __shared__ float s_bias[2][64];
+
+    const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int tiles = tiles_x * tiles_y, nslices = (p.Cout + 63) / 64;
+    const int total = tiles * nslices * p.B;
+    const int cin4 = p.Cin >> 2;  // u32x4 per pixel
+    const u32x4* wt = reinterpret_cast<const u32x4*>(p.Wt);
+
+    struct Item { int b, y0, x0, n0; };
+    auto item_of = [&](int id) {
+        // XCD-contiguous order (xcd_item): ids 8 apart are neighbours on the same L2, cout slice fastest
+        int logical = id;
+        if ((total & 7) == 0) logical = (id & 7) * (total >> 3) + (id >> 3);
+        const int slice = logical % nslices, r = logical / nslices;
+        const int tile = r % tiles;
+        return Item{r / tiles, (tile / tiles_x) * TH, (tile % tiles_x) * TW, slice * 64};
+    };
+
+    // Staging registers: the next stage (possibly the next item's first) is in flight while this one is multiplied
+    u32x4 rin[NIN], rwt[NWT];
+    const int nchunks = p.Cin >> 4;
+    // staging geometry is recomputed from the thread index (a few integer ops) instead of living in registers
+    // through the epilogue: element idx = t + CT*i -> halo pixel (py, px), 16-byte piece q
+    // uniform 64-bit base (SGPRs) + unsigned 32-bit lane offset: one address VGPR per load
+    auto load_in = [&](u32x4 (&r)[NIN], const Item& it, int c) {
+        const u32x4* inb = reinterpret_cast<const u32x4*>(p.in) + (((long long)it.b * p.H + (it.y0 - 1)) * p.W + (it.x0 - 1)) * cin4 + c * 4;
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int idx = t + CT * i, pix = idx >> 2, q = idx & 3;
+            const int py = pix / (TW + 2), px = pix - py * (TW + 2);
+            const int gy = it.y0 + py - 1, gx = it.x0 + px - 1;
+            const bool ok = idx < NPIX * 4 && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+            const unsigned off = (unsigned)((py * p.W + px) * cin4 + q);
+            r[i] = ok ? inb[off] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto load_w = [&](int n0, int c) {
+        const u32x4* wb = wt + ((long long)c * 9 * p.CoutPad + n0) * 4;
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int idx = t + CT * i, row = idx >> 2, q = idx & 3, tap = row >> 6, n = row & 63;
+            const unsigned off = (unsigned)((tap * p.CoutPad + n) * 4 + q);
+            rwt[i] = (idx < 9 * 64 * 4) ? wb[off] : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto store_chunk = [&](const u32x4 (&r)[NIN]) {
+#pragma unroll
+        for (int i = 0; i < NIN; ++i) {
+            const int idx = t + CT * i, pix = idx >> 2, q = idx & 3;
+            const int py = pix / (TW + 2), px = pix - py * (TW + 2);
+            const int P = py * PW + px;
+            if (idx < NPIX * 4) s_in[P * 4 + (q ^ ((P >> 2) & 3))] = r[i];
+        }
+#pragma unroll
+        for (int i = 0; i < NWT; ++i) {
+            const int idx = t + CT * i, row = idx >> 2, q = idx & 3;
+            if (idx < 9 * 64 * 4) s_w[row * 4 + (q ^ ((row >> 2) & 3))] = rwt[i];
+        }
+    };
+    auto load_bias = [&](int n0) { return (t < 64 && n0 + t < p.Cout) ? p.bias[n0 + t] : 0.f; };
+
+    const int wy0 = (wave / WX) * 4, wx0 = (wave % WX) * 16;
+    const int i32 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];  // [cout tile][pixel tile]
+    // pixel operand: lane n -> pixel (dy,dx) = ((n>>1)&1, n&1) of 2x2 block n>>2 (blocks along x)
+    const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
+    // weight operand: row = tap*64 + mt*32 + i32; swizzle term depends on i32 only
+    const int wsw = (i32 >> 2) & 3;
+    const int a_hi = i32 * 4 + ((2 * h) ^ wsw), a_lo = i32 * 4 + ((2 * h + 1) ^ wsw);
+
+    auto multiply = [&]() {
+        const f16x8* si = reinterpret_cast<const f16x8*>(s_in);
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w);
+#pragma unroll KYU
+        for (int ky = 0; ky < 3; ++ky) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                f16x8 bh[2], bl[2], ah[2], al[2];
+#pragma unroll
+                for (int nt = 0; nt < 2; ++nt) {
+                    const int P = P0 + (2 * nt + ky) * PW + kx;
+                    const int sw4 = (P >> 2) & 3;
+                    bh[nt] = si[P * 4 + ((2 * h) ^ sw4)];
+                    bl[nt] = si[P * 4 + ((2 * h + 1) ^ sw4)];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt) {
+                    const int ro = ((ky * 3 + kx) * 64 + mt * 32) * 4;
+                    ah[mt] = sw[ro + a_hi];
+                    al[mt] = sw[ro + a_lo];
+                }
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) mma3(ah[mt], al[mt], bh[nt], bl[nt], acc[mt][nt]);
+            }
+        }
+    };
+
+    int id = blockIdx.x;
+    if (id >= total) return;
+    Item cur = item_of(id);
+    float bias_cur = load_bias(cur.n0), bias_nxt = 0.f;
+    load_w(cur.n0, 0);
+    load_in(rin, cur, 0);
+    for (int k = 0;; ++k) {
+        const bool more = id + (int)gridDim.x < total;
+        const Item nxt = item_of(more ? id + (int)gridDim.x : id);
+        if (t < 64) s_bias[k & 1][t] = bias_cur;  // read by this item's epilogue (barriers in between)
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < nchunks; ++c) {
+            __syncthreads();  // everyone is done reading the previous stage
+            store_chunk(rin);
+            __syncthreads();
+            if (c + 1 < nchunks) {
+                load_w(cur.n0, c + 1);
+                load_in(rin, cur, c + 1);
+            } else if (more) {  // first stage of the next item: in flight under this multiply and the epilogue
+                bias_nxt = load_bias(nxt.n0);
+                load_w(nxt.n0, 0);
+                load_in(rin, nxt, 0);
+            }
+            multiply();
+        }
+        conv_epilogue<GENERIC>(p, acc, s_bias[k & 1], cur.b, cur.y0 + wy0, cur.x0 + wx0, cur.n0, lane);
+        if (!more) break;
+        cur = nxt;
+        bias_cur = bias_nxt;
+        id += gridDim.x;
     }
 }
 
@@ -631,6 +675,16 @@ __global__ __launch_bounds__(256) void conv1a_sh8_kernel(const Conv1aArgs p) {
 
 }  // namespace
 
+static int cu_count() {
+    static int n = 0;
+    if (!n) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    }
+    return n;
+}
+
 void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
     auto waste = [&](int th, int tw) {
         long long ty = (a.H + th - 1) / th, tx = (a.W + tw - 1) / tw;
@@ -642,15 +696,21 @@ void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
     // staging / epilogue phases overlap each other's MFMA phases) is preferred -- measured 7-11 % faster
     // than one 8-wave workgroup per CU on the 240x320 and 120x160 maps.
     const long long w22 = waste(8, 32);
+    const bool generic = !(a.relu && !a.out_f32 && !a.post_scale);  // BatchNorm affine / fp32 output / no ReLU
+    // persistent grid: as many workgroups as fit on the chip at once (LDS: two 4-wave, one 8-wave per CU)
+    auto grid_for = [&](long long items, int per_cu) { return dim3((unsigned)std::min<long long>(items, (long long)cu_count() * per_cu)); };
     if (w22 <= w42 && w22 <= w81) {
-        dim3 grid(((a.H + 7) / 8) * ((a.W + 31) / 32) * nslices * a.B);
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, 2, 1>), grid, dim3(256), 0, s, a);
+        const long long items = (long long)((a.H + 7) / 8) * ((a.W + 31) / 32) * nslices * a.B;
+        if (generic) hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, 2, 1, true>), grid_for(items, 2), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_f16x3_kernel<2, 2, 1, false>), grid_for(items, 2), dim3(256), 0, s, a);
     } else if (w42 <= w81) {
-        dim3 grid(((a.H + 15) / 16) * ((a.W + 31) / 32) * nslices * a.B);
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<4, 2, 3>), grid, dim3(CT), 0, s, a);
+        const long long items = (long long)((a.H + 15) / 16) * ((a.W + 31) / 32) * nslices * a.B;
+        if (generic) hipLaunchKernelGGL((conv3x3_f16x3_kernel<4, 2, 1, true>), grid_for(items, 1), dim3(CT), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_f16x3_kernel<4, 2, 1, false>), grid_for(items, 1), dim3(CT), 0, s, a);
     } else {
-        dim3 grid(((a.H + 31) / 32) * ((a.W + 15) / 16) * nslices * a.B);
-        hipLaunchKernelGGL((conv3x3_f16x3_kernel<8, 1, 1>), grid, dim3(CT), 0, s, a);
+        const long long items = (long long)((a.H + 31) / 32) * ((a.W + 15) / 16) * nslices * a.B;
+        if (generic) hipLaunchKernelGGL((conv3x3_f16x3_kernel<8, 1, 1, true>), grid_for(items, 1), dim3(CT), 0, s, a);
+        else hipLaunchKernelGGL((conv3x3_f16x3_kernel<8, 1, 1, false>), grid_for(items, 1), dim3(CT), 0, s, a);
     }
 }
 
