@@ -37,6 +37,63 @@ __device__ __forceinline__ void xcd_item(int tiles, int nslices, int& tile, int&
 }
 
 
+// One 16-channel chunk of a 3x3 convolution for a wave's 64 couts x 64 pixels: 9 taps x (8 fragment reads, 12
+// MFMAs).  Software-pipelined by hand: the 8 ds_read_b128 of tap k+1 are issued BEFORE the MFMAs of tap k (two
+// fragment sets), and the scheduler is fenced so it cannot sink them back next to their use -- the compiler's own
+// order left 100-200 cycles of LDS latency exposed in front of every tap (measured: multiply phase at 47 % of
+// the MFMA rate).  Per accumulator the products keep the order hi.hi, hi.lo, lo.hi; the four accumulators are
+// interleaved so consecutive MFMAs are independent.
+struct TapFrag {
+    f16x8 bh0, bh1, bl0, bl1, ah0, ah1, al0, al1;
+};
+template <int PW>
+__device__ __forceinline__ void load_tap(TapFrag& f, const f16x8* si, const f16x8* sw, int P0, int h, int a_hi, int a_lo, int tap) {
+    const int ky = tap / 3, kx = tap - 3 * ky;
+    const int Pa = P0 + ky * PW + kx, Pb = Pa + 2 * PW;
+    const int sa = (Pa >> 2) & 3, sb = (Pb >> 2) & 3;
+    f.bh0 = si[Pa * 4 + ((2 * h) ^ sa)];
+    f.bl0 = si[Pa * 4 + ((2 * h + 1) ^ sa)];
+    f.bh1 = si[Pb * 4 + ((2 * h) ^ sb)];
+    f.bl1 = si[Pb * 4 + ((2 * h + 1) ^ sb)];
+    const int ro = tap * 64 * 4;
+    f.ah0 = sw[ro + a_hi];
+    f.al0 = sw[ro + a_lo];
+    f.ah1 = sw[ro + 32 * 4 + a_hi];
+    f.al1 = sw[ro + 32 * 4 + a_lo];
+}
+__device__ __forceinline__ void mma_tap(const TapFrag& f, f32x16 (&acc)[2][2]) {
+    acc[0][0] = mfma16(f.ah0, f.bh0, acc[0][0]);
+    acc[0][1] = mfma16(f.ah0, f.bh1, acc[0][1]);
+    acc[1][0] = mfma16(f.ah1, f.bh0, acc[1][0]);
+    acc[1][1] = mfma16(f.ah1, f.bh1, acc[1][1]);
+    acc[0][0] = mfma16(f.ah0, f.bl0, acc[0][0]);
+    acc[0][1] = mfma16(f.ah0, f.bl1, acc[0][1]);
+    acc[1][0] = mfma16(f.ah1, f.bl0, acc[1][0]);
+    acc[1][1] = mfma16(f.ah1, f.bl1, acc[1][1]);
+    acc[0][0] = mfma16(f.al0, f.bh0, acc[0][0]);
+    acc[0][1] = mfma16(f.al0, f.bh1, acc[0][1]);
+    acc[1][0] = mfma16(f.al1, f.bh0, acc[1][0]);
+    acc[1][1] = mfma16(f.al1, f.bh1, acc[1][1]);
+}
+template <int PW>
+__device__ __forceinline__ void multiply_chunk_pipelined(const f16x8* si, const f16x8* sw, int P0, int h, int a_hi, int a_lo, f32x16 (&acc)[2][2]) {
+    TapFrag f0, f1;
+    load_tap<PW>(f0, si, sw, P0, h, a_hi, a_lo, 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; tap += 2) {
+        if (tap + 1 < 9) load_tap<PW>(f1, si, sw, P0, h, a_hi, a_lo, tap + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma_tap(f0, acc);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap + 1 < 9) {
+            if (tap + 2 < 9) load_tap<PW>(f0, si, sw, P0, h, a_hi, a_lo, tap + 2);
+            __builtin_amdgcn_sched_barrier(0);
+            mma_tap(f1, acc);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+}
+
 // (v[i], v[i+8]) half-wave exchanges of one accumulator tile in one asm block (one hazard gap instead of eight)
 __device__ __forceinline__ void half_swap8(float (&v)[16]) {
     asm volatile(
@@ -395,6 +452,7 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
     __shared__ u32x4 s_in[2][(TH + 2) * PW * 4];
     __shared__ u32x4 s_w[9 * 64 * 4];
     __shared__ float s_g[GH * GP];
+    __shared__ __attribute__((aligned(16))) float s_c1[12 * 64];  // conv1a: [9 taps][64 ch] | bias | post_scale | post_shift
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wave);
@@ -405,6 +463,15 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
     const int n0 = slice * 64;
     const u32x4* wt = reinterpret_cast<const u32x4*>(p.Wt);
 
+    for (int i = t; i < 12 * 64; i += CT) {
+        const int k = i >> 6, ch = i & 63;
+        float v;
+        if (k < 9) v = c1.w[ch * 9 + k];
+        else if (k == 9) v = c1.bias[ch];
+        else if (k == 10) v = c1.post_scale ? c1.post_scale[ch] : 1.f;
+        else v = c1.post_shift ? c1.post_shift[ch] : 0.f;
+        s_c1[i] = v;
+    }
     // gray tile (RGB -> gray as superpoint.py:204-206), zero outside the image
     {
         const long long HW = (long long)c1.H * c1.W;
@@ -439,45 +506,58 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
             if (idx < 9 * 64 * 4) s_w[row * 4 + (q ^ ((row >> 2) & 3))] = rwt[i];
         }
     };
-    // conv1a for chunk c (channels 16c .. 16c+15) over the halo tile -> s_in[buf].  The 8 channels of a
-    // wave are done in two halves of 4 so that their 36 taps + bias/affine stay in SGPRs.
+    // conv1a for chunk c (channels 16c .. 16c+15) over the halo tile -> s_in[buf].  A wave owns one 8-channel
+    // group (uniform) and three halo pixels per lane; the filter taps come from the LDS table s_c1 ([tap][channel],
+    // every lane reads the same address = broadcast) -- as scalar loads they were ~50 dependent round trips per
+    // chunk and made this phase 4x longer than the MFMA phase it is meant to hide under.
     auto produce = [&](int c, int buf) {
         const int gg = wu & 1;              // 8-channel group of this wave (uniform)
         const int ch0 = c * 16 + gg * 8;
         const int hp0 = (wu >> 1) * 64 + lane;
+        int gofs[3];
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const int hp = min(hp0 + 256 * i, NPIX - 1);
+            const int py = hp / (TW + 2), px = hp - py * (TW + 2);
+            gofs[i] = py * GP + px;
+        }
         f32x8 o8[3];
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            float wk[4][9], bs[4], psc[4], psh[4];
+        for (int i = 0; i < 3; ++i) o8[i] = f32x8{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int ch = ch0 + half * 4 + j;
-#pragma unroll
-                for (int k = 0; k < 9; ++k) wk[j][k] = c1.w[ch * 9 + k];
-                bs[j] = c1.bias[ch];
-                psc[j] = c1.post_scale ? c1.post_scale[ch] : 1.f;
-                psh[j] = c1.post_shift ? c1.post_shift[ch] : 0.f;
-            }
+        for (int k = 0; k < 9; ++k) {  // same tap order as the reference accumulation
+            const f32x4 w0 = *reinterpret_cast<const f32x4*>(&s_c1[k * 64 + ch0]);
+            const f32x4 w1 = *reinterpret_cast<const f32x4*>(&s_c1[k * 64 + ch0 + 4]);
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
-                const int hp = min(hp0 + 256 * i, NPIX - 1);
-                const int py = hp / (TW + 2), px = hp - py * (TW + 2);
-                float g[9];
-#pragma unroll
-                for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-                    for (int kx = 0; kx < 3; ++kx) g[ky * 3 + kx] = s_g[(py + ky) * GP + px + kx];
+                const float g = s_g[gofs[i] + (k / 3) * GP + (k % 3)];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    float a = 0.f;
-#pragma unroll
-                    for (int k = 0; k < 9; ++k) a = fmaf(wk[j][k], g[k], a);
-                    a += bs[j];
-                    a = fmaxf(a, 0.f);
-                    if (c1.post_scale) a = __fadd_rn(__fmul_rn(a, psc[j]), psh[j]);
-                    o8[i][half * 4 + j] = a;
+                    o8[i][j] = fmaf(w0[j], g, o8[i][j]);
+                    o8[i][4 + j] = fmaf(w1[j], g, o8[i][4 + j]);
                 }
             }
+        }
+        {
+            const f32x4 b0 = *reinterpret_cast<const f32x4*>(&s_c1[9 * 64 + ch0]), b1 = *reinterpret_cast<const f32x4*>(&s_c1[9 * 64 + ch0 + 4]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o8[i][j] = fmaxf(o8[i][j] + b0[j], 0.f);
+                    o8[i][4 + j] = fmaxf(o8[i][4 + j] + b1[j], 0.f);
+                }
+        }
+        if (c1.post_scale) {  // BatchNorm affine after the ReLU (open variant)
+            const f32x4 s0 = *reinterpret_cast<const f32x4*>(&s_c1[10 * 64 + ch0]), s1 = *reinterpret_cast<const f32x4*>(&s_c1[10 * 64 + ch0 + 4]);
+            const f32x4 t0 = *reinterpret_cast<const f32x4*>(&s_c1[11 * 64 + ch0]), t1 = *reinterpret_cast<const f32x4*>(&s_c1[11 * 64 + ch0 + 4]);
+#pragma unroll
+            for (int i = 0; i < 3; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    o8[i][j] = __fadd_rn(__fmul_rn(o8[i][j], s0[j]), t0[j]);
+                    o8[i][4 + j] = __fadd_rn(__fmul_rn(o8[i][4 + j], s1[j]), t1[j]);
+                }
         }
 #pragma unroll
         for (int i = 0; i < 3; ++i) {
@@ -503,45 +583,7 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
     const int a_hi = i32 * 4 + ((2 * h) ^ wsw), a_lo = i32 * 4 + ((2 * h + 1) ^ wsw);
 
     auto multiply = [&](int buf) {
-        const f16x8* si = reinterpret_cast<const f16x8*>(s_in[buf]);
-        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w);
-#pragma unroll 1
-        for (int ky = 0; ky < 3; ++ky) {
-#pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                f16x8 bh[2], bl[2], ah[2], al[2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int P = P0 + (2 * nt + ky) * PW + kx;
-                    const int sw4 = (P >> 2) & 3;
-#if defined(CONV_ABL) && (CONV_ABL == 1 || CONV_ABL == 2)  // timing experiment: half the pixel-operand reads
-                    if (nt == 1) { bh[1] = bh[0]; bl[1] = bl[0]; continue; }
-#endif
-                    bh[nt] = si[P * 4 + ((2 * h) ^ sw4)];
-                    bl[nt] = si[P * 4 + ((2 * h + 1) ^ sw4)];
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int ro = ((ky * 3 + kx) * 64 + mt * 32) * 4;
-#if defined(CONV_ABL) && CONV_ABL == 2  // timing experiment: half the weight-operand reads too
-                    if (mt == 1) { ah[1] = ah[0]; al[1] = al[0]; continue; }
-#endif
-                    ah[mt] = sw[ro + a_hi];
-                    al[mt] = sw[ro + a_lo];
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-#if defined(CONV_ABL) && CONV_ABL == 3  // timing experiment: one MFMA product instead of three
-                        acc[mt][nt] = mfma16(ah[mt], bh[nt], acc[mt][nt]);
-                        (void)al; (void)bl;
-#else
-                        mma3(ah[mt], al[mt], bh[nt], bl[nt], acc[mt][nt]);
-#endif
-                    }
-            }
-        }
+        multiply_chunk_pipelined<PW>(reinterpret_cast<const f16x8*>(s_in[buf]), reinterpret_cast<const f16x8*>(s_w), P0, h, a_hi, a_lo, acc);
     };
 
     const int nchunks = 4;  // conv1a has 64 output channels
@@ -552,15 +594,29 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
     __syncthreads();
     for (int c = 0; c < nchunks; ++c) {
         const int buf = c & 1;
+#if defined(CONV_ABL) && CONV_ABL == 9    // timing experiment 9: conv1a produced for the first chunk only
+        if (c + 1 < nchunks) load_w(c + 1);
+        multiply(0);
+#elif defined(CONV_ABL) && CONV_ABL == 10  // timing experiment 10: no weight re-staging
+        if (wu < 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
+        multiply(buf);
+        if (wu >= 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
+#elif defined(CONV_ABL) && CONV_ABL == 11  // timing experiment 11: no MFMA phase at all
+        if (c + 1 < nchunks) load_w(c + 1);
+        if (c + 1 < nchunks) produce(c + 1, buf ^ 1);
+#else
         if (c + 1 < nchunks) load_w(c + 1);
         if (wu < 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
         multiply(buf);
         if (wu >= 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
+#endif
         __syncthreads();      // everyone is done with s_w and s_in[buf]
+#if !(defined(CONV_ABL) && CONV_ABL == 10)
         if (c + 1 < nchunks) {
             store_w();
             __syncthreads();
         }
+#endif
     }
 
     // ---- epilogue: identical to conv3x3_f16x3_kernel with pool = 1, SH8 output ----------------------
