@@ -113,8 +113,7 @@ __global__ __launch_bounds__(AT, 2) void attention_f16x3_kernel(const AttnF16Arg
             const int c = (2 * st + h) * 2;
             const f16x8 kh = sk[i32 * 16 + (c ^ (i32 & 15))];
             const f16x8 kl = sk[i32 * 16 + ((c + 1) ^ (i32 & 15))];
-            mma3(kh, kl, qh[0][st], ql[0][st], s[0]);
-            mma3(kh, kl, qh[1][st], ql[1][st], s[1]);
+            mma3x2(kh, kl, qh[0][st], ql[0][st], qh[1][st], ql[1][st], s[0], s[1]);
         }
         const int kleft = Lkv - kt * KT;
         f16x8 ph[2][2], pl[2][2];  // [query tile][k-step]
@@ -165,8 +164,7 @@ __global__ __launch_bounds__(AT, 2) void attention_f16x3_kernel(const AttnF16Arg
                 const int d = dt * 32 + i32, f = (d >> 1) & 7;
                 const f16x8 vh = sv[d * 8 + ((2 * s2 + h) ^ f)];
                 const f16x8 vl = sv[d * 8 + ((4 + 2 * s2 + h) ^ f)];
-                mma3(vh, vl, ph[0][s2], pl[0][s2], o[0][dt]);
-                mma3(vh, vl, ph[1][s2], pl[1][s2], o[1][dt]);
+                mma3x2(vh, vl, ph[0][s2], pl[0][s2], ph[1][s2], pl[1][s2], o[0][dt], o[1][dt]);
             }
         }
         if (kt + 1 < ntiles) store_tile(buf ^ 1);

@@ -68,6 +68,16 @@ __device__ __forceinline__ void mma3(const f16x8 ah, const f16x8 al, const f16x8
     c = mfma16(ah, bl, c);
     c = mfma16(al, bh, c);
 }
+// two accumulators sharing the a operand, products interleaved (consecutive MFMAs independent)
+__device__ __forceinline__ void mma3x2(const f16x8 ah, const f16x8 al, const f16x8 bh0, const f16x8 bl0, const f16x8 bh1, const f16x8 bl1, f32x16& c0,
+                                       f32x16& c1) {
+    c0 = mfma16(ah, bh0, c0);
+    c1 = mfma16(ah, bh1, c1);
+    c0 = mfma16(ah, bl0, c0);
+    c1 = mfma16(ah, bl1, c1);
+    c0 = mfma16(al, bh0, c0);
+    c1 = mfma16(al, bh1, c1);
+}
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split8(const f32x8 v, f16x8& hi, f16x8& lo) {
 #pragma unroll

@@ -367,31 +367,22 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
     const int wsw = (i32 >> 2) & 3;
     const int a_hi = i32 * 4 + ((2 * h) ^ wsw), a_lo = i32 * 4 + ((2 * h + 1) ^ wsw);
 
+    // KYU == 0 selects the hand-pipelined tap loop (32 more VGPRs for the second fragment set: the 8-wave tiles
+    // have room for it, the 4-wave tile with its larger per-thread staging share does not)
     auto multiply = [&]() {
         const f16x8* si = reinterpret_cast<const f16x8*>(s_in);
         const f16x8* sw = reinterpret_cast<const f16x8*>(s_w);
+        if constexpr (KYU == 0) {
+            multiply_chunk_pipelined<PW>(si, sw, P0, h, a_hi, a_lo, acc);
+        } else {
 #pragma unroll KYU
-        for (int ky = 0; ky < 3; ++ky) {
+            for (int ky = 0; ky < 3; ++ky) {
 #pragma unroll
-            for (int kx = 0; kx < 3; ++kx) {
-                f16x8 bh[2], bl[2], ah[2], al[2];
-#pragma unroll
-                for (int nt = 0; nt < 2; ++nt) {
-                    const int P = P0 + (2 * nt + ky) * PW + kx;
-                    const int sw4 = (P >> 2) & 3;
-                    bh[nt] = si[P * 4 + ((2 * h) ^ sw4)];
-                    bl[nt] = si[P * 4 + ((2 * h + 1) ^ sw4)];
+                for (int kx = 0; kx < 3; ++kx) {
+                    TapFrag f;
+                    load_tap<PW>(f, si, sw, P0, h, a_hi, a_lo, ky * 3 + kx);
+                    mma_tap(f, acc);
                 }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    const int ro = ((ky * 3 + kx) * 64 + mt * 32) * 4;
-                    ah[mt] = sw[ro + a_hi];
-                    al[mt] = sw[ro + a_lo];
-                }
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) mma3(ah[mt], al[mt], bh[nt], bl[nt], acc[mt][nt]);
             }
         }
     };

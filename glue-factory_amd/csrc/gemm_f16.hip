@@ -167,10 +167,19 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
             bh[tt] = st[swz(row, 2 * h)];
             bl[tt] = st[swz(row, 2 * h + 1)];
         }
+        // product-major: consecutive MFMAs hit different accumulators; per accumulator the order stays hi.hi, hi.lo, lo.hi
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) mma3(ah[ft], al[ft], bh[tt], bl[tt], acc[ft][tt]);
+            for (int tt = 0; tt < 2; ++tt) acc[ft][tt] = mfma16(ah[ft], bh[tt], acc[ft][tt]);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) acc[ft][tt] = mfma16(ah[ft], bl[tt], acc[ft][tt]);
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int tt = 0; tt < 2; ++tt) acc[ft][tt] = mfma16(al[ft], bh[tt], acc[ft][tt]);
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
