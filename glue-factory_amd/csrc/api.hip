@@ -619,7 +619,7 @@ int run_detect(mg_context* h, const mg_sp_conf* conf, const float* heat, int B, 
 // ================================================================================================
 extern "C" {
 
-int mg_abi_version(void) { return 3; }
+int mg_abi_version(void) { return 4; }
 
 const char* mg_last_error(void) { return g_err.c_str(); }
 
@@ -1185,6 +1185,59 @@ int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const
         a.m0 = reinterpret_cast<long long*>(matches0); a.m1 = reinterpret_cast<long long*>(matches1);
         a.ms0 = mscores0; a.ms1 = mscores1;
         launch_assign_filter(a, s);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mg_nn_forward(mg_handle h, const mg_nn_conf* conf, const float* desc0, const float* desc1, int B, int M, int N, int D, int64_t* matches0,
+                  int64_t* matches1, float* mscores0, float* mscores1, float* similarity, float* log_assignment, void* stream) {
+    if (!h || !conf || !desc0 || !desc1 || !matches0 || !matches1 || !mscores0 || !mscores1) return fail(MG_ERR_ARG, "NULL argument");
+    if (B < 1 || M < 1 || N < 1 || D < 16 || (D & 15)) return fail(MG_ERR_ARG, "bad shape (descriptor dim must be a multiple of 16)");
+    if (conf->ratio_thresh > 0.f && (M < 2 || N < 2))
+        return fail(MG_ERR_ARG, "ratio test needs two candidates per side (the reference's topk(2) raises as well)");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool f16 = h->precision == MG_PREC_F16X3;
+    const size_t T0 = (size_t)B * M, T1 = (size_t)B * N;
+    float* SIM = similarity ? similarity : h->buf("lg.sim", (size_t)B * M * N);
+    float* ST = h->buf("lg.stats", 6 * (T0 + T1) + 16);
+    if (!SIM || !ST) return fail(MG_ERR_HIP, "workspace allocation failed");
+    {
+        ProfScope ps(h, s, "nn.gemm.sim");
+        if (f16) {
+            float* DS = h->buf("nn.desc", (T0 + T1) * D);
+            if (!DS) return fail(MG_ERR_HIP, "workspace allocation failed");
+            launch_to_sh8(desc0, DS, (long long)T0 * D, s);
+            launch_to_sh8(desc1, DS + T0 * D, (long long)T1 * D, s);
+            GemmF16Args g;
+            g.A0 = DS; g.lda0 = D; g.ksplit = D;
+            g.W = DS + T0 * D; g.w_rowmajor = 1; g.ldw = D;
+            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = D;
+            g.batch = B; g.strideA = (long long)M * D; g.strideW = (long long)N * D; g.strideC = (long long)M * N;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g;
+            g.A0 = desc0; g.lda0 = D; g.ksplit = D;
+            g.W = desc1; g.w_rowmajor = 1; g.ldw = D;
+            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = D;
+            g.batch = B; g.strideA = (long long)M * D; g.strideW = (long long)N * D; g.strideC = (long long)M * N;
+            launch_gemm(g, s);
+        }
+    }
+    {
+        ProfScope ps(h, s, "nn.match");
+        NnArgs a;
+        a.sim = SIM; a.B = B; a.M = M; a.N = N;
+        a.use_ratio = conf->ratio_thresh > 0.f; a.use_dist = conf->distance_thresh > 0.f; a.mutual = conf->mutual_check != 0;
+        a.ratio2 = (float)((double)conf->ratio_thresh * (double)conf->ratio_thresh);
+        a.dist2 = (float)((double)conf->distance_thresh * (double)conf->distance_thresh);
+        a.row_lse = ST; a.col_lse = ST + T0;
+        a.cand0 = reinterpret_cast<int*>(ST + T0 + T1); a.cand1 = a.cand0 + T0;
+        a.m0 = reinterpret_cast<long long*>(matches0); a.m1 = reinterpret_cast<long long*>(matches1);
+        a.ms0 = mscores0; a.ms1 = mscores1; a.la = log_assignment;
+        launch_nn_match(a, s);
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -217,3 +217,21 @@ struct SinkhornArgs {
 size_t sinkhorn_work_floats(int B, int M, int N);
 void launch_sinkhorn(const SinkhornArgs& a, hipStream_t s);
 void launch_assign_filter(const AssignArgs& a, hipStream_t s);
+
+// ---- nn_misc.hip : nearest-neighbour matcher on a (B,M,N) similarity matrix ---------------------
+struct NnArgs {
+    const float* sim = nullptr;
+    int B = 0, M = 0, N = 0;
+    float ratio2 = 0.f, dist2 = 0.f;  // squared thresholds (fp32 of the double square, as torch casts the scalar)
+    int use_ratio = 0, use_dist = 0, mutual = 1;
+    float* row_lse = nullptr;  // (B,M) workspace
+    float* col_lse = nullptr;  // (B,N)
+    int* cand0 = nullptr;      // (B,M)
+    int* cand1 = nullptr;      // (B,N)
+    long long* m0 = nullptr;
+    long long* m1 = nullptr;
+    float* ms0 = nullptr;
+    float* ms1 = nullptr;
+    float* la = nullptr;       // optional (B,M+1,N+1)
+};
+void launch_nn_match(const NnArgs& a, hipStream_t s);

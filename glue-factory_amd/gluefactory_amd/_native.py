@@ -20,7 +20,7 @@ MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN = 0, 1, 2
 # every symbol include/matchglue.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_precision", "mg_set_weight", "mg_weights_ready",
-    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_sg_forward", "mg_debug_request", "mg_debug_read",
+    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_sg_forward", "mg_nn_forward", "mg_debug_request", "mg_debug_read",
     "mg_profile_enable", "mg_profile_read", "mg_test_linear",
 ]
 
@@ -42,6 +42,10 @@ class LgConf(Structure):
 
 class SgConf(Structure):
     _fields_ = [("n_layers", c_int32), ("sinkhorn_iterations", c_int32), ("filter_threshold", c_float)]
+
+
+class NnConf(Structure):
+    _fields_ = [("ratio_thresh", c_float), ("distance_thresh", c_float), ("mutual_check", c_int32)]
 
 
 _lib = None
@@ -71,6 +75,7 @@ def lib():
     L.mg_sp_sample.argtypes = [c_void_p, POINTER(SpConf), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.mg_lg_forward.argtypes = [c_void_p, POINTER(LgConf)] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 8
     L.mg_sg_forward.argtypes = [c_void_p, POINTER(SgConf)] + [c_void_p] * 8 + [c_int] * 3 + [c_void_p] * 7
+    L.mg_nn_forward.argtypes = [c_void_p, POINTER(NnConf), c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 7
     L.mg_debug_request.argtypes = [c_void_p, c_char_p]
     L.mg_debug_read.argtypes = [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]
     L.mg_profile_enable.argtypes = [c_void_p, c_int]
@@ -225,6 +230,24 @@ class Engine:
         _check(lib().mg_sg_forward(self._h, ctypes.byref(conf), _ptr(k0), _ptr(k1), _ptr(d0), _ptr(d1), _ptr(sc0), _ptr(sc1), _ptr(s0),
                                    _ptr(s1), B, M, N, _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1), _ptr(la), _ptr(cost), _stream(dev)))
         return m0, m1, ms0, ms1, la, cost
+
+    # -- nearest-neighbour matcher ----------------------------------------------------------------
+    def nn_forward(self, conf, d0, d1, want_similarity=True, want_log_assignment=True):
+        dev = self.device
+        d0, d1 = _f32(d0, dev), _f32(d1, dev)
+        B, M, D = d0.shape
+        N = d1.shape[1]
+        if d1.shape[0] != B or d1.shape[2] != D:
+            raise RuntimeError(f"descriptor shapes do not agree: {tuple(d0.shape)} / {tuple(d1.shape)}")
+        m0 = torch.empty(B, M, dtype=torch.int64, device=dev)
+        m1 = torch.empty(B, N, dtype=torch.int64, device=dev)
+        ms0 = torch.empty(B, M, device=dev)
+        ms1 = torch.empty(B, N, device=dev)
+        sim = torch.empty(B, M, N, device=dev) if want_similarity else None
+        la = torch.empty(B, M + 1, N + 1, device=dev) if want_log_assignment else None
+        _check(lib().mg_nn_forward(self._h, ctypes.byref(conf), _ptr(d0), _ptr(d1), B, M, N, D, _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1),
+                                   _ptr(sim), _ptr(la), _stream(dev)))
+        return m0, m1, ms0, ms1, sim, la
 
     # -- introspection ---------------------------------------------------------------------------
     def debug_request(self, tap):

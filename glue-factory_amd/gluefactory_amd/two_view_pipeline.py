@@ -18,6 +18,8 @@ _ALIASES = {
     "matchers.lightglue": "gluefactory_amd.lightglue",
     "gluefactory.models.matchers.lightglue": "gluefactory_amd.lightglue",
     "gluefactory_nonfree.superglue": "gluefactory_amd.superglue",
+    "matchers.nearest_neighbor_matcher": "gluefactory_amd.nearest_neighbor_matcher",
+    "gluefactory.models.matchers.nearest_neighbor_matcher": "gluefactory_amd.nearest_neighbor_matcher",
 }
 
 

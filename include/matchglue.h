@@ -138,6 +138,20 @@ int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const
                   int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment,
                   float* sinkhorn_cost, void* stream);
 
+/* -- nearest-neighbour matcher ------------------------------------------------
+ * gluefactory/models/matchers/nearest_neighbor_matcher.py:51-72: sim = desc0 . desc1^T, best (and second best for
+ * the ratio test) per row and per column, thresholds on d = 2(1 - sim), optional mutual check. No weights.
+ * desc0 (B,M,D), desc1 (B,N,D), D a multiple of 16. A threshold <= 0 is "off" (the reference's None).
+ * similarity optional (B,M,N); log_assignment optional (B,M+1,N+1) (double log-softmax, zero last row/column). */
+typedef struct mg_nn_conf {
+    float ratio_thresh;
+    float distance_thresh;
+    int32_t mutual_check;
+} mg_nn_conf;
+int mg_nn_forward(mg_handle h, const mg_nn_conf* conf, const float* desc0, const float* desc1, int B, int M, int N, int D,
+                  int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* similarity,
+                  float* log_assignment, void* stream);
+
 /* -- introspection ----------------------------------------------------------------------------
  * Copy a named internal buffer of the LAST forward into `dst` (device, fp32), for stage-wise
  * parity tests: "lg.enc" (tokens,64), "lg.self<i>" / "lg.layer<i>" (tokens,256) descriptors after

@@ -638,3 +638,37 @@ def make_sg_weights(seed=0, n_layers=18, final_gain=6.0, bin_score=1.0):
     W["final_proj.bias"] = torch.zeros(256)
     W["bin_score"] = torch.tensor(float(bin_score))
     return W
+
+
+# --------------------------------------------------------------------------
+# Nearest-neighbour matcher
+# --------------------------------------------------------------------------
+def _nn_find(sim, ratio_thresh, distance_thresh):
+    """nearest_neighbor_matcher.py:15-26."""
+    sim_nn, ind_nn = sim.topk(2 if ratio_thresh else 1, dim=-1, largest=True)
+    dist_nn = 2 * (1 - sim_nn)
+    mask = torch.ones(ind_nn.shape[:-1], dtype=torch.bool)
+    if ratio_thresh:
+        mask = mask & (dist_nn[..., 0] <= (ratio_thresh ** 2) * dist_nn[..., 1])
+    if distance_thresh:
+        mask = mask & (dist_nn[..., 0] <= distance_thresh ** 2)
+    return torch.where(mask, ind_nn[..., 0], ind_nn.new_tensor(-1))
+
+
+def nn_forward(data, ratio_thresh=None, distance_thresh=None, mutual_check=True):
+    """nearest_neighbor_matcher.py:51-72 (mutual check :29-36)."""
+    sim = torch.einsum("bnd,bmd->bnm", data["descriptors0"], data["descriptors1"])
+    m0 = _nn_find(sim, ratio_thresh, distance_thresh)
+    m1 = _nn_find(sim.transpose(1, 2), ratio_thresh, distance_thresh)
+    if mutual_check:
+        i0 = torch.arange(m0.shape[-1])
+        i1 = torch.arange(m1.shape[-1])
+        loop0 = torch.gather(m1, -1, torch.where(m0 > -1, m0, m0.new_tensor(0)))
+        loop1 = torch.gather(m0, -1, torch.where(m1 > -1, m1, m1.new_tensor(0)))
+        m0, m1 = (torch.where((m0 > -1) & (i0 == loop0), m0, m0.new_tensor(-1)),
+                  torch.where((m1 > -1) & (i1 == loop1), m1, m1.new_tensor(-1)))
+    b, m, n = sim.shape
+    la = sim.new_zeros(b, m + 1, n + 1)
+    la[:, :-1, :-1] = F.log_softmax(sim, -1) + F.log_softmax(sim, -2)
+    return {"matches0": m0, "matches1": m1, "matching_scores0": (m0 > -1).float(), "matching_scores1": (m1 > -1).float(),
+            "similarity": sim, "log_assignment": la}

@@ -266,6 +266,28 @@ def gold_superglue():
 
 
 # ---------------------------------------------------------------- (5) two-view pipeline on the boat pair
+def gold_nn():
+    """gluefactory/models/matchers/nearest_neighbor_matcher.py run as is; descriptors with clear margins
+    (noisy permuted copies) so that the arg-maxes do not hinge on the last bit of a dot product."""
+    Ref = get_model("matchers.nearest_neighbor_matcher")
+    arrs = {}
+    for tag, B, M, N, D, seed in (("a", 2, 48, 40, 256, 21), ("b", 1, 100, 131, 128, 22), ("c", 3, 17, 64, 64, 23)):
+        g = torch.Generator().manual_seed(seed)
+        d0 = torch.nn.functional.normalize(torch.randn(B, M, D, generator=g), dim=-1)
+        perm = torch.stack([torch.randperm(max(M, N), generator=g)[:N] % M for _ in range(B)])
+        d1 = torch.gather(d0, 1, perm[..., None].expand(-1, -1, D)) + (0.7 / D ** 0.5) * torch.randn(B, N, D, generator=g)
+        d1 = torch.nn.functional.normalize(d1, dim=-1)
+        arrs[f"{tag}.descriptors0"], arrs[f"{tag}.descriptors1"] = d0, d1
+        for ci, conf in enumerate(({}, {"ratio_thresh": 0.9}, {"distance_thresh": 0.8}, {"ratio_thresh": 0.95, "distance_thresh": 0.9, "mutual_check": False})):
+            p = Ref(conf).eval()({"descriptors0": d0, "descriptors1": d1})
+            for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+                arrs[f"{tag}.c{ci}.{k}"] = p[k]
+            if ci == 0:
+                arrs[f"{tag}.similarity"] = p["similarity"]
+                arrs[f"{tag}.log_assignment"] = p["log_assignment"]
+    save("nn_matcher", **arrs)
+
+
 def gold_two_view(boat):
     g0 = np.round(boat[0].astype(np.float32) @ np.array([0.299, 0.587, 0.114], np.float32)).astype(np.uint8)
     g1 = np.round(boat[1].astype(np.float32) @ np.array([0.299, 0.587, 0.114], np.float32)).astype(np.uint8)
@@ -320,4 +342,5 @@ if __name__ == "__main__":
     gold_superpoint(boat)
     gold_lightglue()
     gold_superglue()
+    gold_nn()
     gold_two_view(boat)

@@ -162,3 +162,19 @@ def test_superglue_matches_reference(golden):
                 torch.testing.assert_close(p[k], g[f"{tag}.th{th}.{k}"], rtol=0, atol=1e-5)
         torch.testing.assert_close(p["sinkhorn_cost"], g[tag + ".sinkhorn_cost"], rtol=1e-5, atol=1e-4)
         torch.testing.assert_close(p["log_assignment"], g[tag + ".log_assignment"], rtol=1e-5, atol=1e-4)
+
+
+NN_CONFS = ({}, {"ratio_thresh": 0.9}, {"distance_thresh": 0.8}, {"ratio_thresh": 0.95, "distance_thresh": 0.9, "mutual_check": False})
+
+
+def test_nn_matcher_matches_reference(golden):
+    """gluefactory/models/matchers/nearest_neighbor_matcher.py run by oracle/tools/make_goldens.py."""
+    g = golden("nn_matcher")
+    for tag in ("a", "b", "c"):
+        data = {"descriptors0": g[tag + ".descriptors0"], "descriptors1": g[tag + ".descriptors1"]}
+        for ci, conf in enumerate(NN_CONFS):
+            p = O.nn_forward(data, **conf)
+            for k in ("matches0", "matches1", "matching_scores0", "matching_scores1"):
+                assert torch.equal(p[k], g[f"{tag}.c{ci}.{k}"]), (tag, ci, k)
+        torch.testing.assert_close(p["similarity"], g[tag + ".similarity"], rtol=0, atol=2e-6)
+        torch.testing.assert_close(p["log_assignment"], g[tag + ".log_assignment"], rtol=0, atol=1e-5)
