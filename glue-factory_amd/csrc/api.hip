@@ -245,7 +245,11 @@ int prep_linear_rows(mg_context* h, const std::vector<const float*>& rows, const
             }
         if (int rc = upload(h, sh, &L->Wh)) return rc;
     }
-    if (!bias.empty()) return upload(h, bias, &L->bias);
+    if (!bias.empty()) {
+        std::vector<float> bp(L->Npad, 0.f);  // padded: a launch may round N up to a multiple of 32 (zero weights, zero bias)
+        std::copy(bias.begin(), bias.end(), bp.begin());
+        return upload(h, bp, &L->bias);
+    }
     return 0;
 }
 
@@ -767,7 +771,10 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
     float* f4 = h->buf("sp.f4", n8 * 128);
     float* cP = h->buf("sp.cP", n8 * 256);
     float* cD = h->buf("sp.cD", n8 * 256);
-    float* lg = h->buf("sp.logits", n8 * 65);
+    // detector logits: 65 channels; the f16x3 GEMM writes rows of 96 (N rounded up to its 32-feature blocks, zero
+    // weights / bias in the padding) so that it stays on the straight-line epilogue instead of the ragged-N path
+    const int ldl = (h->precision == MG_PREC_F16X3 && !h->convPb.ps) ? 96 : 65;
+    float* lg = h->buf("sp.logits", n8 * 96);
     float* dd = h->buf("sp.dense", n8 * 256);
     float* heat = h->buf("sp.heat", n8 * 64);
     if (!a1 || !p1 || !a2 || !p2 || !a3 || !p3 || !a4 || !f4 || !cP || !cD || !lg || !dd || !heat) return fail(MG_ERR_HIP, "workspace allocation failed");
@@ -819,7 +826,7 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
         ProfScope ps(h, s, "sp.convPb");
         if (f16) {
             GemmF16Args g = lin_args_f16(h->convPb, cP, 256, (int)n8);
-            g.C = lg; g.ldc = 65;
+            g.C = lg; g.ldc = ldl; g.N = ldl;
             launch_gemm_f16x3(g, s);
         } else {
             GemmArgs g = lin_args(h->convPb, cP, 256, (int)n8, lg, 65);
@@ -828,7 +835,7 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
     }
     {
         ProfScope ps(h, s, "sp.softmax_d2s");
-        launch_softmax_d2s(lg, 65, B, hc, wc, heat, s);
+        launch_softmax_d2s(lg, ldl, B, hc, wc, heat, s);
     }
     {
         ProfScope ps(h, s, "sp.convDb");
