@@ -337,6 +337,47 @@ def test_two_view_boat_golden(dev, golden, variant, precision):
         torch.testing.assert_close(p["matching_scores0"].cpu(), g[variant + ".shift.matching_scores0"], rtol=0, atol=1e-3)
 
 
+def test_two_view_config3_padded_vs_oracle(dev):
+    """BASELINE.json configs[2] shape: 1024x1024 square-padded images whose valid region is 1024x768
+    (`image_size`, honoured by the border mask superpoint.py:243-254), 2048 keypoints, one pair against the oracle."""
+    from gluefactory_amd.two_view_pipeline import TwoViewPipeline
+
+    g = torch.Generator().manual_seed(31)
+    base = torch.nn.functional.avg_pool2d(torch.rand(1, 1, 772 + 40, 1028 + 40, generator=g), 5, 1)
+    base = (base - base.amin()) / (base.amax() - base.amin())
+    im0 = torch.zeros(1, 1, 1024, 1024)
+    im1 = torch.zeros(1, 1, 1024, 1024)
+    im0[:, :, :768, :] = base[:, :, 0:768, 0:1024]
+    im1[:, :, :768, :] = base[:, :, 24:792, 16:1040]  # shifted copy: genuine correspondences
+    size = torch.tensor([[1024.0, 768.0]])
+    W_sp, W_lg = O.make_sp_weights(0), O.make_lg_weights(7, structured=True, final_gain=8.0, match_bias=2.0)
+    spc = dict(nms_radius=3, detection_threshold=0.0, max_num_keypoints=2048)
+    data = {"view0": {"image": im0, "image_size": size}, "view1": {"image": im1, "image_size": size}}
+    ref = O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1))
+    pipe = TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint", **spc},
+                            "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1}}).eval()
+    pipe.extractor.load_state_dict(W_sp)
+    pipe.matcher.load_state_dict(W_lg)
+    to = lambda x: {k: (to(v) if isinstance(v, dict) else v.to(dev)) for k, v in x.items()}
+    p = pipe(to(data))
+    assert p["keypoints0"].shape == (1, 2048, 2) and p["matches0"].shape == (1, 2048)
+    # nothing is detected in the padding or within 4 px of the valid region's border
+    for k in ("keypoints0", "keypoints1"):
+        kp = p[k][0].cpu() - 0.5
+        assert kp[:, 1].max() < 768 - 4 and kp[:, 0].max() < 1024 - 4 and kp.min() >= 4
+        a, c = set(map(tuple, p[k][0].cpu().tolist())), set(map(tuple, ref[k][0].tolist()))
+        same = (p[k].cpu() == ref[k]).all(-1).float().mean().item()
+        print(f"{k}: set overlap {len(a & c)}/2048, same rank {same:.4f}")
+        assert len(a & c) >= 2028 and same > 0.97
+    kp_same = all((p[k].cpu() == ref[k]).all() for k in ("keypoints0", "keypoints1"))
+    m_same = (p["matches0"].cpu() == ref["matches0"]).float().mean().item()
+    print(f"matches identical {m_same:.4f}, matched {(ref['matches0'] > -1).sum().item()} (keypoints identical: {kp_same})")
+    assert (ref["matches0"] > -1).sum() > 500
+    assert m_same > 0.97
+    if kp_same:
+        assert m_same == 1.0
+
+
 def test_fused_views_equal_separate_calls(dev):
     """One 2B-image extractor launch == two B-image launches (two_view_pipeline.py:73-74), bit for bit."""
     from gluefactory_amd.two_view_pipeline import TwoViewPipeline
