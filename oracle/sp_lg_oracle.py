@@ -672,3 +672,145 @@ def nn_forward(data, ratio_thresh=None, distance_thresh=None, mutual_check=True)
     la[:, :-1, :-1] = F.log_softmax(sim, -1) + F.log_softmax(sim, -2)
     return {"matches0": m0, "matches1": m1, "matching_scores0": (m0 > -1).float(), "matching_scores1": (m1 > -1).float(),
             "similarity": sim, "log_assignment": la}
+
+
+# --------------------------------------------------------------------------
+# GlueStick: points + line endpoints in one graph
+# --------------------------------------------------------------------------
+def gs_log_double_softmax(scores, bin_score):
+    """gluestick.py:758-770 -- mean of the row / column log-softmax, each with its own dustbin."""
+    b, m, n = scores.shape
+    bin_ = bin_score[None, None, None]
+    s0 = F.log_softmax(torch.cat([scores, bin_.expand(b, m, 1)], 2), 2)
+    s1 = F.log_softmax(torch.cat([scores, bin_.expand(b, 1, n)], 1), 1)
+    out = scores.new_full((b, m + 1, n + 1), 0)
+    out[:, :m, :n] = (s0[:, :, :n] + s1[:, :m, :]) / 2
+    out[:, :-1, -1] = s0[:, :, -1]
+    out[:, -1, :-1] = s1[:, -1, :]
+    return out
+
+
+def _gs_endpoint_encoding(lines, scores, W):
+    """gluestick.py:498-517 -- per endpoint [x, y, dx, dy, score] -> MLP; lines (B,n,2,2) normalised."""
+    b, n = lines.shape[:2]
+    off = (lines[:, :, 1] - lines[:, :, 0]).unsqueeze(2)
+    off = torch.cat([off, -off], 2).reshape(b, 2 * n, 2).transpose(1, 2)
+    x = torch.cat([lines.flatten(1, 2).transpose(1, 2), off, scores.repeat(1, 2).unsqueeze(1)], 1)
+    return _sg_mlp(x, W, "lenc.encoder", 5)
+
+
+def _gs_line_layer(d, enc, idx, W, p):
+    """gluestick.py:581-612, 656-689 (line_attention=False): message per endpoint = [own junction, the line's other
+    junction, endpoint encoding] -> MLP([768,512,256]) -> mean over the endpoints that share a junction."""
+    b, dim = d.shape[:2]
+    ld = torch.gather(d, 2, idx[:, None].repeat(1, dim, 1))
+    ld2 = ld.reshape(b, dim, -1, 2).flip([-1]).flatten(2, 3)
+    upd = _sg_mlp(torch.cat([ld, ld2, enc], 1), W, p + ".mlp", 2)
+    out = torch.zeros_like(d).scatter_reduce_(2, idx[:, None].repeat(1, dim, 1), upd, reduce="mean", include_self=False)
+    return d + out
+
+
+def _gs_line_scores(ld0, ld1, idx0, idx1, W, proj):
+    """gluestick.py:331-373 -- endpoint similarity, gathered per line, best of the two endpoint orders."""
+    m0 = F.conv1d(ld0, W[proj + ".weight"], W[proj + ".bias"])
+    m1 = F.conv1d(ld1, W[proj + ".weight"], W[proj + ".bias"])
+    s = torch.einsum("bdn,bdm->bnm", m0, m1) / 256 ** 0.5
+    n0, n1 = idx0.shape[1], idx1.shape[1]
+    s = torch.gather(s, 2, idx1[:, None, :].repeat(1, s.shape[1], 1))
+    s = torch.gather(s, 1, idx0[:, :, None].repeat(1, 1, n1))
+    s = s.reshape(-1, n0 // 2, 2, n1 // 2, 2)
+    return 0.5 * torch.maximum(s[:, :, 0, :, 0] + s[:, :, 1, :, 1], s[:, :, 0, :, 1] + s[:, :, 1, :, 0])
+
+
+GS_DEFAULTS = dict(n_layers=18, filter_threshold=0.2)
+
+
+def gluestick_forward(data, W, **conf):
+    """gluestick.py:136-312 (input_dim == descriptor_dim == 256, num_line_iterations 1, no line attention,
+    no intermediate supervision) for inputs with at least one keypoint and one line per image."""
+    cfg = {**GS_DEFAULTS, **conf}
+    d0 = data["descriptors0"].transpose(-1, -2)
+    d1 = data["descriptors1"].transpose(-1, -2)
+    b = d0.shape[0]
+    s0, s1 = data["view0"]["image_size"], data["view1"]["image_size"]
+    n0, n1 = data["lines0"].shape[1], data["lines1"].shape[1]
+    idx0, idx1 = data["lines_junc_idx0"].flatten(1, 2), data["lines_junc_idx1"].flatten(1, 2)
+    k0 = sg_normalize_keypoints(data["keypoints0"], s0)
+    k1 = sg_normalize_keypoints(data["keypoints1"], s1)
+    d0 = d0 + _sg_mlp(torch.cat([k0.transpose(1, 2), data["keypoint_scores0"].unsqueeze(1)], 1), W, "kenc.encoder", 5)
+    d1 = d1 + _sg_mlp(torch.cat([k1.transpose(1, 2), data["keypoint_scores1"].unsqueeze(1)], 1), W, "kenc.encoder", 5)
+    l0 = sg_normalize_keypoints(data["lines0"].flatten(1, 2), s0).reshape(b, n0, 2, 2)
+    l1 = sg_normalize_keypoints(data["lines1"].flatten(1, 2), s1).reshape(b, n1, 2, 2)
+    e0 = _gs_endpoint_encoding(l0, data["line_scores0"], W)
+    e1 = _gs_endpoint_encoding(l1, data["line_scores1"], W)
+    taps = {"kenc": (d0.clone(), d1.clone()), "lenc": (e0.clone(), e1.clone())}
+    for i in range(cfg["n_layers"]):
+        p = f"gnn.layers.{i}.update"
+        if i % 2 == 0:
+            u0, u1 = _sg_propagate(d0, d0, W, p), _sg_propagate(d1, d1, W, p)
+        else:
+            u0, u1 = _sg_propagate(d0, d1, W, p), _sg_propagate(d1, d0, W, p)
+        d0, d1 = d0 + u0, d1 + u1
+        if i % 2 == 0:
+            q = f"gnn.line_layers.{i // 2}"
+            d0, d1 = _gs_line_layer(d0, e0, idx0, W, q), _gs_line_layer(d1, e1, idx1, W, q)
+        if i in (0, 1, cfg["n_layers"] - 1):
+            taps[i] = (d0.clone(), d1.clone())
+    m0 = F.conv1d(d0, W["final_proj.weight"], W["final_proj.bias"])
+    m1 = F.conv1d(d1, W["final_proj.weight"], W["final_proj.bias"])
+    S = gs_log_double_softmax(torch.einsum("bdn,bdm->bnm", m0, m1) / 256 ** 0.5, W["bin_score"])
+    mt0, mt1, ms0, ms1, _, _ = filter_matches(S, cfg["filter_threshold"])
+    raw = _gs_line_scores(d0[:, :, : 2 * n0], d1[:, :, : 2 * n1], idx0, idx1, W, "final_line_proj")
+    LS = gs_log_double_softmax(raw, W["line_bin_score"])
+    lt0, lt1, ls0, ls1, _, _ = filter_matches(LS, cfg["filter_threshold"])
+    return {"log_assignment": S, "matches0": mt0, "matches1": mt1, "matching_scores0": ms0, "matching_scores1": ms1,
+            "line_log_assignment": LS, "line_matches0": lt0, "line_matches1": lt1, "line_matching_scores0": ls0,
+            "line_matching_scores1": ls1, "raw_line_scores": raw, "_taps": taps}
+
+
+def make_gs_weights(seed=0, n_layers=18, final_gain=6.0, bin_score=1.0, line_bin_score=0.5):
+    """Seeded GlueStick weights under the reference's state_dict key names (gluestick.py:62-100, 459-470, 561-700)."""
+    g = torch.Generator().manual_seed(seed)
+    W = {}
+
+    def conv(name, co, ci, gain=1.0, zero_bias=False):
+        W[name + ".weight"] = torch.randn(co, ci, 1, generator=g) * gain / math.sqrt(ci)
+        W[name + ".bias"] = torch.zeros(co) if zero_bias else torch.randn(co, generator=g) * 0.05
+
+    def bn(name, c):
+        W[name + ".weight"] = 0.75 + 0.5 * torch.rand(c, generator=g)
+        W[name + ".bias"] = 0.2 * (torch.rand(c, generator=g) - 0.5)
+        W[name + ".running_mean"] = 0.2 * (torch.rand(c, generator=g) - 0.5)
+        W[name + ".running_var"] = 0.5 + torch.rand(c, generator=g)
+        W[name + ".num_batches_tracked"] = torch.tensor(0)
+
+    for enc, cin in (("kenc", 3), ("lenc", 5)):
+        chans = [cin, 32, 64, 128, 256, 256]
+        idx = 0
+        for i in range(5):
+            conv(f"{enc}.encoder.{idx}", chans[i + 1], chans[i], gain=0.3 if i == 4 else 1.4, zero_bias=(i == 4))
+            idx += 1
+            if i < 4:
+                bn(f"{enc}.encoder.{idx}", chans[i + 1])
+                idx += 2
+    for l in range(n_layers):
+        p = f"gnn.layers.{l}.update"
+        conv(p + ".attn.merge", 256, 256, gain=0.5)
+        for j in range(3):
+            conv(p + f".attn.proj.{j}", 256, 256, gain=1.0)
+        conv(p + ".mlp.0", 512, 512, gain=1.4)
+        bn(p + ".mlp.1", 512)
+        conv(p + ".mlp.3", 256, 512, gain=0.3, zero_bias=True)
+    for l in range(n_layers // 2):
+        p = f"gnn.line_layers.{l}"
+        conv(p + ".mlp.0", 512, 768, gain=1.4)
+        bn(p + ".mlp.1", 512)
+        conv(p + ".mlp.3", 256, 512, gain=0.3, zero_bias=True)
+    eye = torch.eye(256)[:, :, None]
+    W["final_proj.weight"] = final_gain * eye + 0.05 * torch.randn(256, 256, 1, generator=g)
+    W["final_proj.bias"] = torch.zeros(256)
+    W["final_line_proj.weight"] = final_gain * eye + 0.05 * torch.randn(256, 256, 1, generator=g)
+    W["final_line_proj.bias"] = torch.zeros(256)
+    W["bin_score"] = torch.tensor(float(bin_score))
+    W["line_bin_score"] = torch.tensor(float(line_bin_score))
+    return W

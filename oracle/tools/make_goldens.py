@@ -266,6 +266,58 @@ def gold_superglue():
 
 
 # ---------------------------------------------------------------- (5) two-view pipeline on the boat pair
+def gs_inputs(B, M, N, n0, n1, seed, share=0.6):
+    """Synthetic wireframe-style inputs: the first junctions of the keypoint list are line endpoints
+    (`lines_junc_idx` < 2 * n_lines, several endpoints share a junction), image 1 is a noisy re-ordering of image 0."""
+    g = torch.Generator().manual_seed(300 + seed)
+    size0 = torch.tensor([[640.0, 480.0]] * B)
+    size1 = torch.tensor([[600.0, 480.0]] * B)
+    K = max(M, N)
+    kk = torch.rand(B, K, 2, generator=g) * size1[:, None] * 0.98 + 0.5
+    dd = torch.nn.functional.normalize(torch.randn(B, K, 256, generator=g), dim=-1)
+    k0, d0 = kk[:, :M].contiguous(), dd[:, :M].contiguous()
+    perm = torch.stack([torch.randperm(K, generator=g)[:N] for _ in range(B)])
+    k1 = (torch.gather(kk, 1, perm[..., None].expand(-1, -1, 2)) * 0.9 + 3.0 * torch.randn(B, N, 2, generator=g)).clamp(1.0, 479.0)
+    d1 = torch.nn.functional.normalize(torch.gather(dd, 1, perm[..., None].expand(-1, -1, 256)) + 0.05 * torch.randn(B, N, 256, generator=g), dim=-1)
+    out = {"keypoints0": k0, "keypoints1": k1, "descriptors0": d0, "descriptors1": d1,
+           "keypoint_scores0": torch.rand(B, M, generator=g), "keypoint_scores1": torch.rand(B, N, generator=g),
+           "view0": {"image_size": size0}, "view1": {"image_size": size1}}
+    for side, n, kp in (("0", n0, k0), ("1", n1, k1)):
+        J = max(2, int(2 * n * share))  # junctions actually used (< 2n: endpoints share junctions)
+        idx = torch.randint(0, J, (B, n, 2), generator=g)
+        idx[:, :, 1] = torch.where(idx[:, :, 1] == idx[:, :, 0], (idx[:, :, 1] + 1) % J, idx[:, :, 1])
+        out["lines_junc_idx" + side] = idx
+        out["lines" + side] = torch.gather(kp, 1, idx.reshape(B, 2 * n)[..., None].expand(-1, -1, 2)).reshape(B, n, 2, 2)
+        out["line_scores" + side] = torch.rand(B, n, generator=g)
+    return out
+
+
+def gold_gluestick():
+    Ref = get_model("matchers.gluestick")
+    arrs = {}
+    for tag, B, M, N, n0, n1, seed in (("a", 2, 48, 40, 10, 8, 1), ("b", 1, 64, 64, 16, 16, 2), ("c", 2, 33, 70, 5, 12, 3)):
+        W = O.make_gs_weights(seed)
+        data = gs_inputs(B, M, N, n0, n1, seed)
+        for k, v in data.items():
+            if k.startswith("view"):
+                arrs[f"{tag}.size{k[-1]}"] = v["image_size"]
+            else:
+                arrs[f"{tag}.{k}"] = v
+        for th in (0.0, 0.2):
+            m = Ref({"weights": None, "filter_threshold": th}).eval()
+            missing, unexpected = m.load_state_dict(W, strict=False)
+            assert not missing and not unexpected, (missing, unexpected)
+            p = m(data)
+            for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "line_matches0", "line_matches1",
+                      "line_matching_scores0", "line_matching_scores1"):
+                arrs[f"{tag}.th{th}.{k}"] = p[k]
+            if th == 0.0:
+                for k in ("log_assignment", "line_log_assignment", "raw_line_scores"):
+                    arrs[f"{tag}.{k}"] = p[k]
+        print("gluestick", tag, "matches", int((p["matches0"] > -1).sum()), "of", B * M, "line matches", int((p["line_matches0"] > -1).sum()), "of", B * n0)
+    save("gluestick", **arrs)
+
+
 def gold_nn():
     """gluefactory/models/matchers/nearest_neighbor_matcher.py run as is; descriptors with clear margins
     (noisy permuted copies) so that the arg-maxes do not hinge on the last bit of a dot product."""
@@ -343,4 +395,5 @@ if __name__ == "__main__":
     gold_lightglue()
     gold_superglue()
     gold_nn()
+    gold_gluestick()
     gold_two_view(boat)

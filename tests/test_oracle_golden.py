@@ -178,3 +178,29 @@ def test_nn_matcher_matches_reference(golden):
                 assert torch.equal(p[k], g[f"{tag}.c{ci}.{k}"]), (tag, ci, k)
         torch.testing.assert_close(p["similarity"], g[tag + ".similarity"], rtol=0, atol=2e-6)
         torch.testing.assert_close(p["log_assignment"], g[tag + ".log_assignment"], rtol=0, atol=1e-5)
+
+
+def _gs_data(g, tag):
+    d = {k: g[f"{tag}.{k}"] for k in ("keypoints0", "keypoints1", "descriptors0", "descriptors1", "keypoint_scores0", "keypoint_scores1",
+                                     "lines0", "lines1", "lines_junc_idx0", "lines_junc_idx1", "line_scores0", "line_scores1")}
+    d["view0"], d["view1"] = {"image_size": g[tag + ".size0"]}, {"image_size": g[tag + ".size1"]}
+    return d
+
+
+GS_INT = ("matches0", "matches1", "line_matches0", "line_matches1")
+GS_FLT = ("matching_scores0", "matching_scores1", "line_matching_scores0", "line_matching_scores1")
+
+
+def test_gluestick_matches_reference(golden):
+    """gluefactory/models/matchers/gluestick.py run by oracle/tools/make_goldens.py."""
+    g = golden("gluestick")
+    for tag, seed in (("a", 1), ("b", 2), ("c", 3)):
+        W = O.make_gs_weights(seed)
+        for th in (0.0, 0.2):
+            p = O.gluestick_forward(_gs_data(g, tag), W, filter_threshold=th)
+            for k in GS_INT:
+                assert torch.equal(p[k], g[f"{tag}.th{th}.{k}"]), (tag, th, k)
+            for k in GS_FLT:
+                torch.testing.assert_close(p[k], g[f"{tag}.th{th}.{k}"], rtol=0, atol=1e-5)
+        for k in ("log_assignment", "line_log_assignment", "raw_line_scores"):
+            torch.testing.assert_close(p[k], g[f"{tag}.{k}"], rtol=1e-5, atol=1e-4)
