@@ -93,7 +93,7 @@ struct ProfEntry {
 struct mg_context {
     int device = 0;
     int precision = MG_PREC_F16X3;
-    std::map<std::string, HostTensor> raw[3];
+    std::map<std::string, HostTensor> raw[4];
     std::vector<void*> owned;  // device allocations of prepared weights
 
     // SuperPoint
@@ -115,6 +115,14 @@ struct mg_context {
     std::vector<SgLayer> sg_gnn;
     LinLayer sg_final;
     float sg_bin = 1.f;
+    // GlueStick
+    int gs_layers = -1;
+    LinLayer gs_kenc[5], gs_lenc[5];
+    struct GsLine { LinLayer mlp0, mlp3; };
+    std::vector<SgLayer> gs_gnn;
+    std::vector<GsLine> gs_line;
+    LinLayer gs_final, gs_final_line;
+    float gs_bin = 1.f, gs_line_bin = 1.f;
 
     // workspace
     std::map<std::string, DevBuf> ws;
@@ -429,12 +437,12 @@ int prepare_lg(mg_context* h, int n_layers) {
 // folded into mlp.0 exactly like LightGlue's out-projection (the message only feeds the MLP, :139-141).
 struct BnFold { std::vector<double> s, t; };
 
-int sg_bn(mg_context* h, const std::string& prefix, int C, BnFold* out) {
+int sg_bn(mg_context* h, int which, const std::string& prefix, int C, BnFold* out) {
     const HostTensor *g, *b, *m, *v;
-    if (int rc = need(h, 2, prefix + ".weight", {C}, &g)) return rc;
-    if (int rc = need(h, 2, prefix + ".bias", {C}, &b)) return rc;
-    if (int rc = need(h, 2, prefix + ".running_mean", {C}, &m)) return rc;
-    if (int rc = need(h, 2, prefix + ".running_var", {C}, &v)) return rc;
+    if (int rc = need(h, which, prefix + ".weight", {C}, &g)) return rc;
+    if (int rc = need(h, which, prefix + ".bias", {C}, &b)) return rc;
+    if (int rc = need(h, which, prefix + ".running_mean", {C}, &m)) return rc;
+    if (int rc = need(h, which, prefix + ".running_var", {C}, &v)) return rc;
     out->s.resize(C);
     out->t.resize(C);
     for (int c = 0; c < C; ++c) {
@@ -457,95 +465,118 @@ int sg_linear(mg_context* h, const std::vector<std::vector<double>>& W, const st
     return prep_linear_rows(h, rows, bf, Kpad, L);
 }
 
+// Conv1d(k=1) `name` (N x K) with an optional BatchNorm1d `bn_name` folded in; K padded up to Kpad
+int sg_prep_conv(mg_context* h, int which, const std::string& name, int N, int K, const std::string& bn_name, int Kpad, LinLayer* out) {
+    const HostTensor *w, *b;
+    if (int rc = need(h, which, name + ".weight", {N, K, 1}, &w)) return rc;
+    if (int rc = need(h, which, name + ".bias", {N}, &b)) return rc;
+    BnFold bn;
+    const bool has_bn = !bn_name.empty();
+    if (has_bn)
+        if (int rc = sg_bn(h, which, bn_name, N, &bn)) return rc;
+    std::vector<std::vector<double>> W(N, std::vector<double>(K));
+    std::vector<double> bias(N);
+    for (int n = 0; n < N; ++n) {
+        const double sc = has_bn ? bn.s[n] : 1.0, t = has_bn ? bn.t[n] : 0.0;
+        for (int k = 0; k < K; ++k) W[n][k] = (double)w->data[(size_t)n * K + k] * sc;
+        bias[n] = (double)b->data[n] * sc + t;
+    }
+    *out = LinLayer();
+    return sg_linear(h, W, bias, Kpad, out);
+}
+
+// MLP([cin, 32, 64, 128, 256, 256]) of the keypoint / endpoint encoders (superglue.py:89-97, gluestick.py:488-517)
+int sg_prep_encoder(mg_context* h, int which, const std::string& prefix, int cin, LinLayer* out5) {
+    const int chans[6] = {cin, 32, 64, 128, 256, 256};
+    for (int i = 0; i < 5; ++i) {
+        const std::string cn = prefix + "." + std::to_string(3 * i);
+        const std::string bn = i < 4 ? prefix + "." + std::to_string(3 * i + 1) : std::string();
+        if (int rc = sg_prep_conv(h, which, cn, chans[i + 1], chans[i], bn, chans[i] < 32 ? 32 : chans[i], &out5[i])) return rc;
+    }
+    return 0;
+}
+
+// one AttentionalPropagation block under prefix `p` (superglue.py:118-141, gluestick.py:520-560)
+int sg_prep_layer(mg_context* h, int which, const std::string& p, mg_context::SgLayer* L) {
+    // [q ; k ; v] with rows re-ordered to [head][dim]
+    std::vector<std::vector<double>> W(768, std::vector<double>(256));
+    std::vector<double> bias(768);
+    for (int part = 0; part < 3; ++part) {
+        const HostTensor *w, *b;
+        if (int rc = need(h, which, p + ".attn.proj." + std::to_string(part) + ".weight", {256, 256, 1}, &w)) return rc;
+        if (int rc = need(h, which, p + ".attn.proj." + std::to_string(part) + ".bias", {256}, &b)) return rc;
+        for (int hd = 0; hd < 4; ++hd)
+            for (int d = 0; d < 64; ++d) {
+                const int nn = part * 256 + hd * 64 + d, old = d * 4 + hd;
+                for (int k = 0; k < 256; ++k) W[nn][k] = w->data[(size_t)old * 256 + k];
+                bias[nn] = b->data[old];
+            }
+    }
+    if (int rc = sg_linear(h, W, bias, 256, &L->proj)) return rc;
+    // mlp.0 with merge folded in (context columns re-ordered to [head][dim]) and BatchNorm folded on top
+    const HostTensor *w0, *b0, *wm, *bm;
+    if (int rc = need(h, which, p + ".mlp.0.weight", {512, 512, 1}, &w0)) return rc;
+    if (int rc = need(h, which, p + ".mlp.0.bias", {512}, &b0)) return rc;
+    if (int rc = need(h, which, p + ".attn.merge.weight", {256, 256, 1}, &wm)) return rc;
+    if (int rc = need(h, which, p + ".attn.merge.bias", {256}, &bm)) return rc;
+    BnFold bn;
+    if (int rc = sg_bn(h, which, p + ".mlp.1", 512, &bn)) return rc;
+    std::vector<std::vector<double>> W0(512, std::vector<double>(512));
+    std::vector<double> bias0(512);
+    for (int n = 0; n < 512; ++n) {
+        const float* wn = w0->data.data() + (size_t)n * 512;
+        for (int k = 0; k < 256; ++k) W0[n][k] = (double)wn[k] * bn.s[n];
+        for (int hd = 0; hd < 4; ++hd)
+            for (int d = 0; d < 64; ++d) {
+                double acc = 0.0;
+                for (int j = 0; j < 256; ++j) acc += (double)wn[256 + j] * (double)wm->data[(size_t)j * 256 + d * 4 + hd];
+                W0[n][256 + hd * 64 + d] = acc * bn.s[n];
+            }
+        double bb = b0->data[n];
+        for (int j = 0; j < 256; ++j) bb += (double)wn[256 + j] * (double)bm->data[j];
+        bias0[n] = bb * bn.s[n] + bn.t[n];
+    }
+    if (int rc = sg_linear(h, W0, bias0, 512, &L->mlp0f)) return rc;
+    return sg_prep_conv(h, which, p + ".mlp.3", 256, 512, "", 512, &L->mlp3);
+}
+
 int prepare_sg(mg_context* h, int n_layers) {
     if (h->sg_layers == n_layers) return 0;
-    const int chans[6] = {3, 32, 64, 128, 256, 256};
-    const int conv_idx[5] = {0, 3, 6, 9, 12};
-    for (int i = 0; i < 5; ++i) {
-        const int ci = chans[i], co = chans[i + 1];
-        const std::string cn = "kenc.encoder." + std::to_string(conv_idx[i]);
-        const HostTensor *w, *b;
-        if (int rc = need(h, 2, cn + ".weight", {co, ci, 1}, &w)) return rc;
-        if (int rc = need(h, 2, cn + ".bias", {co}, &b)) return rc;
-        BnFold bn;
-        const bool has_bn = i < 4;
-        if (has_bn)
-            if (int rc = sg_bn(h, "kenc.encoder." + std::to_string(conv_idx[i] + 1), co, &bn)) return rc;
-        std::vector<std::vector<double>> W(co, std::vector<double>(ci));
-        std::vector<double> bias(co);
-        for (int n = 0; n < co; ++n) {
-            const double s = has_bn ? bn.s[n] : 1.0, t = has_bn ? bn.t[n] : 0.0;
-            for (int k = 0; k < ci; ++k) W[n][k] = (double)w->data[(size_t)n * ci + k] * s;
-            bias[n] = (double)b->data[n] * s + t;
-        }
-        h->sg_kenc[i] = LinLayer();
-        if (int rc = sg_linear(h, W, bias, ci < 32 ? 32 : ci, &h->sg_kenc[i])) return rc;
-    }
+    if (int rc = sg_prep_encoder(h, 2, "kenc.encoder", 3, h->sg_kenc)) return rc;
     h->sg_gnn.assign(n_layers, mg_context::SgLayer());
-    for (int l = 0; l < n_layers; ++l) {
-        const std::string p = "gnn.layers." + std::to_string(l);
-        // [q ; k ; v] with rows re-ordered to [head][dim]
-        std::vector<std::vector<double>> W(768, std::vector<double>(256));
-        std::vector<double> bias(768);
-        for (int which = 0; which < 3; ++which) {
-            const HostTensor *w, *b;
-            if (int rc = need(h, 2, p + ".attn.proj." + std::to_string(which) + ".weight", {256, 256, 1}, &w)) return rc;
-            if (int rc = need(h, 2, p + ".attn.proj." + std::to_string(which) + ".bias", {256}, &b)) return rc;
-            for (int hd = 0; hd < 4; ++hd)
-                for (int d = 0; d < 64; ++d) {
-                    const int nn = which * 256 + hd * 64 + d, old = d * 4 + hd;
-                    for (int k = 0; k < 256; ++k) W[nn][k] = w->data[(size_t)old * 256 + k];
-                    bias[nn] = b->data[old];
-                }
-        }
-        if (int rc = sg_linear(h, W, bias, 256, &h->sg_gnn[l].proj)) return rc;
-        // mlp.0 with merge folded in (context columns re-ordered to [head][dim]) and BatchNorm folded on top
-        const HostTensor *w0, *b0, *wm, *bm, *w3, *b3;
-        if (int rc = need(h, 2, p + ".mlp.0.weight", {512, 512, 1}, &w0)) return rc;
-        if (int rc = need(h, 2, p + ".mlp.0.bias", {512}, &b0)) return rc;
-        if (int rc = need(h, 2, p + ".attn.merge.weight", {256, 256, 1}, &wm)) return rc;
-        if (int rc = need(h, 2, p + ".attn.merge.bias", {256}, &bm)) return rc;
-        BnFold bn;
-        if (int rc = sg_bn(h, p + ".mlp.1", 512, &bn)) return rc;
-        std::vector<std::vector<double>> W0(512, std::vector<double>(512));
-        std::vector<double> bias0(512);
-        for (int n = 0; n < 512; ++n) {
-            const float* wn = w0->data.data() + (size_t)n * 512;
-            for (int k = 0; k < 256; ++k) W0[n][k] = (double)wn[k] * bn.s[n];
-            for (int hd = 0; hd < 4; ++hd)
-                for (int d = 0; d < 64; ++d) {
-                    double acc = 0.0;
-                    for (int j = 0; j < 256; ++j) acc += (double)wn[256 + j] * (double)wm->data[(size_t)j * 256 + d * 4 + hd];
-                    W0[n][256 + hd * 64 + d] = acc * bn.s[n];
-                }
-            double bb = b0->data[n];
-            for (int j = 0; j < 256; ++j) bb += (double)wn[256 + j] * (double)bm->data[j];
-            bias0[n] = bb * bn.s[n] + bn.t[n];
-        }
-        if (int rc = sg_linear(h, W0, bias0, 512, &h->sg_gnn[l].mlp0f)) return rc;
-        if (int rc = need(h, 2, p + ".mlp.3.weight", {256, 512, 1}, &w3)) return rc;
-        if (int rc = need(h, 2, p + ".mlp.3.bias", {256}, &b3)) return rc;
-        std::vector<std::vector<double>> W3(256, std::vector<double>(512));
-        std::vector<double> bias3(256);
-        for (int n = 0; n < 256; ++n) {
-            for (int k = 0; k < 512; ++k) W3[n][k] = w3->data[(size_t)n * 512 + k];
-            bias3[n] = b3->data[n];
-        }
-        if (int rc = sg_linear(h, W3, bias3, 512, &h->sg_gnn[l].mlp3)) return rc;
-    }
-    const HostTensor *wf, *bf, *bs;
-    if (int rc = need(h, 2, "final_proj.weight", {256, 256, 1}, &wf)) return rc;
-    if (int rc = need(h, 2, "final_proj.bias", {256}, &bf)) return rc;
+    for (int l = 0; l < n_layers; ++l)
+        if (int rc = sg_prep_layer(h, 2, "gnn.layers." + std::to_string(l), &h->sg_gnn[l])) return rc;
+    if (int rc = sg_prep_conv(h, 2, "final_proj", 256, 256, "", 256, &h->sg_final)) return rc;
+    const HostTensor* bs;
     if (int rc = need(h, 2, "bin_score", {1}, &bs)) return rc;
-    std::vector<std::vector<double>> Wf(256, std::vector<double>(256));
-    std::vector<double> biasf(256);
-    for (int n = 0; n < 256; ++n) {
-        for (int k = 0; k < 256; ++k) Wf[n][k] = wf->data[(size_t)n * 256 + k];
-        biasf[n] = bf->data[n];
-    }
-    if (int rc = sg_linear(h, Wf, biasf, 256, &h->sg_final)) return rc;
     h->sg_bin = bs->data[0];
     h->sg_layers = n_layers;
+    return 0;
+}
+
+// GlueStick (gluefactory/models/matchers/gluestick.py:62-100): SuperGlue's blocks under `gnn.layers.{i}.update`, an
+// endpoint encoder, one line layer per self layer (MLP([768, 512, 256]) with BatchNorm), two final projections.
+int prepare_gs(mg_context* h, int n_layers) {
+    if (h->gs_layers == n_layers) return 0;
+    if (int rc = sg_prep_encoder(h, 3, "kenc.encoder", 3, h->gs_kenc)) return rc;
+    if (int rc = sg_prep_encoder(h, 3, "lenc.encoder", 5, h->gs_lenc)) return rc;
+    h->gs_gnn.assign(n_layers, mg_context::SgLayer());
+    for (int l = 0; l < n_layers; ++l)
+        if (int rc = sg_prep_layer(h, 3, "gnn.layers." + std::to_string(l) + ".update", &h->gs_gnn[l])) return rc;
+    h->gs_line.assign((n_layers + 1) / 2, mg_context::GsLine());
+    for (int l = 0; l < (n_layers + 1) / 2; ++l) {
+        const std::string p = "gnn.line_layers." + std::to_string(l);
+        if (int rc = sg_prep_conv(h, 3, p + ".mlp.0", 512, 768, p + ".mlp.1", 768, &h->gs_line[l].mlp0)) return rc;
+        if (int rc = sg_prep_conv(h, 3, p + ".mlp.3", 256, 512, "", 512, &h->gs_line[l].mlp3)) return rc;
+    }
+    if (int rc = sg_prep_conv(h, 3, "final_proj", 256, 256, "", 256, &h->gs_final)) return rc;
+    if (int rc = sg_prep_conv(h, 3, "final_line_proj", 256, 256, "", 256, &h->gs_final_line)) return rc;
+    const HostTensor *bs, *lbs;
+    if (int rc = need(h, 3, "bin_score", {1}, &bs)) return rc;
+    if (int rc = need(h, 3, "line_bin_score", {1}, &lbs)) return rc;
+    h->gs_bin = bs->data[0];
+    h->gs_line_bin = lbs->data[0];
+    h->gs_layers = n_layers;
     return 0;
 }
 
@@ -623,7 +654,7 @@ int run_detect(mg_context* h, const mg_sp_conf* conf, const float* heat, int B, 
 // ================================================================================================
 extern "C" {
 
-int mg_abi_version(void) { return 4; }
+int mg_abi_version(void) { return 5; }
 
 const char* mg_last_error(void) { return g_err.c_str(); }
 
@@ -658,12 +689,12 @@ int mg_set_precision(mg_handle h, int mode) {
 }
 
 int mg_set_weight(mg_handle h, int which, const char* key, const float* data, const int64_t* shape, int ndim) {
-    if (!h || !key || !data || which < 0 || which > 2 || ndim < 0 || (ndim > 0 && !shape)) return fail(MG_ERR_ARG, "bad argument");
+    if (!h || !key || !data || which < 0 || which > 3 || ndim < 0 || (ndim > 0 && !shape)) return fail(MG_ERR_ARG, "bad argument");
     HostTensor t;
     t.shape.assign(shape, shape + ndim);
     t.data.assign(data, data + t.numel());
     h->raw[which][key] = std::move(t);
-    if (which == 0) h->sp_variant = -1; else if (which == 1) h->lg_layers = -1; else h->sg_layers = -1;  // re-tile on next use
+    if (which == 0) h->sp_variant = -1; else if (which == 1) h->lg_layers = -1; else if (which == 2) h->sg_layers = -1; else h->gs_layers = -1;  // re-tile on next use
     return 0;
 }
 
@@ -672,6 +703,7 @@ int mg_weights_ready(mg_handle h, int which, int variant_or_layers) {
     HIPCHK(hipSetDevice(h->device));
     if (which == 0) return prepare_sp(h, variant_or_layers);
     if (which == 2) return prepare_sg(h, variant_or_layers > 0 ? variant_or_layers : 18);
+    if (which == 3) return prepare_gs(h, variant_or_layers > 0 ? variant_or_layers : 18);
     return prepare_lg(h, variant_or_layers > 0 ? variant_or_layers : 9);
 }
 
@@ -1192,6 +1224,206 @@ int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const
         a.m0 = reinterpret_cast<long long*>(matches0); a.m1 = reinterpret_cast<long long*>(matches1);
         a.ms0 = mscores0; a.ms1 = mscores1;
         launch_assign_filter(a, s);
+    }
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
+                  const float* scores0, const float* scores1, const float* size0, const float* size1, const float* lines0, const float* lines1,
+                  const int64_t* junc_idx0, const int64_t* junc_idx1, const float* line_scores0, const float* line_scores1, int B, int M, int N,
+                  int n0, int n1, int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment,
+                  int64_t* line_matches0, int64_t* line_matches1, float* line_mscores0, float* line_mscores1, float* line_log_assignment,
+                  float* raw_line_scores, void* stream) {
+    if (!h || !conf || !kpts0 || !kpts1 || !desc0 || !desc1 || !scores0 || !scores1 || !size0 || !size1 || !matches0 || !matches1 ||
+        !mscores0 || !mscores1)
+        return fail(MG_ERR_ARG, "NULL argument (GlueStick needs keypoint scores and image sizes)");
+    if (B < 1 || M < 1 || N < 1 || n0 < 0 || n1 < 0 || conf->n_layers < 1) return fail(MG_ERR_ARG, "bad shape / configuration");
+    const bool lines = n0 > 0 && n1 > 0;  // gluestick.py:203, :735-739: the line branch needs lines in both images
+    if (lines) {
+        if (!lines0 || !lines1 || !junc_idx0 || !junc_idx1 || !line_scores0 || !line_scores1 || !line_matches0 || !line_matches1 ||
+            !line_mscores0 || !line_mscores1)
+            return fail(MG_ERR_ARG, "NULL line argument");
+        if (2 * n0 > M || 2 * n1 > N)
+            return fail(MG_ERR_ARG, "line junctions must be the first 2*n_lines keypoints (gluestick.py:262-263 slices them off the front)");
+    }
+    HIPCHK(hipSetDevice(h->device));
+    if (int rc = prepare_gs(h, conf->n_layers)) return rc;
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const bool f16 = h->precision == MG_PREC_F16X3;
+
+    const size_t T0 = (size_t)B * M, T1 = (size_t)B * N, T = T0 + T1;
+    const size_t E0 = (size_t)B * 2 * n0, E = lines ? E0 + (size_t)B * 2 * n1 : 0;
+    float* X = h->buf("lg.x", T * 256);
+    float* XS = h->buf("lg.xs", T * 256);
+    float* QKV = h->buf("lg.qkv", T * 768);
+    float* CTX = h->buf("lg.ctx", T * 256);
+    float* HID = h->buf("lg.hid", T * 512);
+    float* P0 = h->buf("lg.msg", T * 256);
+    float* SIM = h->buf("lg.sim", (size_t)B * M * N);
+    float* ST = h->buf("lg.stats", 6 * T + 16);
+    if (!X || !XS || !QKV || !CTX || !HID || !P0 || !SIM || !ST) return fail(MG_ERR_HIP, "workspace allocation failed");
+    float *ENC = nullptr, *MSG = nullptr, *LH = nullptr, *UPD = nullptr, *LT = nullptr;
+    if (lines) {
+        ENC = h->buf("gs.enc", E * 256);
+        MSG = h->buf("gs.msg", E * 768);
+        LH = h->buf("gs.hid", E * 512);
+        UPD = h->buf("gs.upd", E * 256);
+        LT = h->buf("gs.tmp", E * 256 + E * 64);
+        if (!ENC || !MSG || !LH || !UPD || !LT) return fail(MG_ERR_HIP, "workspace allocation failed");
+    }
+
+    // one dispatcher for both arithmetic modes; "act" buffers hold SH8 in f16x3 mode and fp32 otherwise
+    struct Opt { int relu = 0; float scale = 1.f; int scale_cols = 0; const float* residual = nullptr; float* c32 = nullptr; int ldc32 = 0; };
+    auto linear = [&](const LinLayer& L, size_t rows, const float* A, int lda, const float* A1, int lda1, float* act_out, int ld_out, const Opt& o) {
+        if (f16) {
+            GemmF16Args g = lin_args_f16(L, A, lda, (int)rows);
+            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
+            g.Cs = act_out; g.ldcs = ld_out; g.C = o.c32; g.ldc = o.ldc32;
+            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
+            launch_gemm_f16x3(g, s);
+        } else {
+            float* out = o.c32 ? o.c32 : act_out;
+            GemmArgs g = lin_args(L, A, lda, (int)rows, out, o.c32 ? o.ldc32 : ld_out);
+            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
+            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
+            launch_gemm(g, s);
+        }
+    };
+    // MLP([cin->32, 64, 128, 256, 256]) on `rows` input rows of 32 floats; the last layer goes where `last` says
+    auto encoder = [&](const LinLayer* enc, size_t rows, float* in32, float* in_sh8, float* t0, float* t1, float* last_act, const Opt& last) {
+        const float* a = in32;
+        if (f16) { launch_to_sh8(in32, in_sh8, (long long)rows * 32, s); a = in_sh8; }
+        Opt relu; relu.relu = 1;
+        linear(enc[0], rows, a, 32, nullptr, 0, t0, 32, relu);
+        linear(enc[1], rows, t0, 32, nullptr, 0, t1, 64, relu);
+        linear(enc[2], rows, t1, 64, nullptr, 0, t0, 128, relu);
+        linear(enc[3], rows, t0, 128, nullptr, 0, t1, 256, relu);
+        linear(enc[4], rows, t1, 256, nullptr, 0, last_act, 256, last);
+    };
+    float* XA = f16 ? XS : X;  // the GEMM-input view of the descriptor stream
+
+    HIPCHK(hipMemcpyAsync(X, desc0, T0 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(X + T0 * 256, desc1, T1 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    {   // keypoint encoder: desc += MLP([x, y, score])  (gluestick.py:199-200)
+        ProfScope ps(h, s, "gs.kenc");
+        float* KIN = HID;
+        launch_sg_kenc_input(kpts0, kpts1, scores0, scores1, size0, size1, B, M, N, KIN, s);
+        Opt last; last.residual = X; last.c32 = X; last.ldc32 = 256;
+        encoder(h->gs_kenc, T, KIN, HID + T * 32, P0, CTX, XS, last);
+    }
+    if (int rc = tap_copy(h, "gs.kenc", X, T * 256, s)) return rc;
+    if (lines) {  // endpoint encodings (gluestick.py:204-212), kept for every line layer
+        ProfScope ps(h, s, "gs.lenc");
+        float* LIN = LT;  // (E,32) fp32 followed by its SH8 copy
+        launch_gs_lenc_input(lines0, lines1, line_scores0, line_scores1, size0, size1, B, n0, n1, LIN, s);
+        Opt last;
+        if (!f16) { last.c32 = ENC; last.ldc32 = 256; }
+        encoder(h->gs_lenc, E, LIN, LIN + E * 32, MSG, LH, ENC, last);
+    }
+
+    for (int l = 0; l < conf->n_layers; ++l) {
+        const mg_context::SgLayer& Lr = h->gs_gnn[l];
+        const int cross = l & 1;  // GNN_layers = ["self", "cross"] * 9
+        {
+            ProfScope ps(h, s, "gs.gemm.qkv");
+            Opt o; o.scale = f16 ? 0.125f * 1.4426950408889634f : 0.125f; o.scale_cols = 256;
+            linear(Lr.proj, T, XA, 256, nullptr, 0, QKV, 768, o);
+        }
+        {
+            ProfScope ps(h, s, cross ? "gs.attn.cross" : "gs.attn.self");
+            if (f16) {
+                AttnF16Args a;
+                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
+                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+                launch_attention_f16x3(a, s);
+            } else {
+                AttnArgs a;
+                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
+                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+                launch_attention(a, s);
+            }
+        }
+        {
+            ProfScope ps(h, s, "gs.gemm.mlp");
+            Opt o; o.relu = 1;
+            linear(Lr.mlp0f, T, XA, 256, CTX, 256, HID, 512, o);
+            Opt r; r.residual = X; r.c32 = X; r.ldc32 = 256;
+            linear(Lr.mlp3, T, HID, 512, nullptr, 0, XS, 256, r);
+        }
+        if (!cross && lines) {  // line layer after every self layer (gluestick.py:719-741), num_line_iterations = 1
+            ProfScope ps(h, s, "gs.line_layer");
+            const mg_context::GsLine& Ll = h->gs_line[l / 2];
+            GsLineArgs a;
+            a.B = B; a.M = M; a.N = N; a.n0 = n0; a.n1 = n1;
+            a.idx0 = reinterpret_cast<const long long*>(junc_idx0); a.idx1 = reinterpret_cast<const long long*>(junc_idx1);
+            a.x = XA; a.enc = ENC; a.msg = MSG; a.upd = UPD; a.x32 = X; a.xs = f16 ? XS : nullptr;
+            launch_gs_gather_msg(a, s);
+            Opt o; o.relu = 1;
+            if (!f16) { o.c32 = LH; o.ldc32 = 512; }
+            linear(Ll.mlp0, E, MSG, 768, nullptr, 0, LH, 512, o);
+            Opt u; u.c32 = UPD; u.ldc32 = 256;
+            linear(Ll.mlp3, E, LH, 512, nullptr, 0, nullptr, 0, u);
+            launch_gs_scatter_mean(a, s);
+        }
+        if (int rc = tap_copy(h, "gs.layer" + std::to_string(l), X, T * 256, s)) return rc;
+    }
+
+    auto sim_gemm = [&](const float* MD, size_t rowsA, size_t rowsW, float* out) {  // out[b] = MD0[b,:rowsA] . MD1[b,:rowsW]^T / 16
+        if (f16) {
+            GemmF16Args g;
+            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+            g.C = out; g.ldc = (int)rowsW; g.M = (int)rowsA; g.N = (int)rowsW; g.K = 256;
+            g.scale = 0.0625f; g.scale_cols = (int)rowsW;
+            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)rowsA * rowsW;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g;
+            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+            g.C = out; g.ldc = (int)rowsW; g.M = (int)rowsA; g.N = (int)rowsW; g.K = 256;
+            g.scale = 0.0625f; g.scale_cols = (int)rowsW;
+            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)rowsA * rowsW;
+            launch_gemm(g, s);
+        }
+    };
+    auto assign = [&](const float* scores, float bin, int m, int n, float* la, int64_t* mt0, int64_t* mt1, float* sc0, float* sc1) {
+        const size_t r0 = (size_t)B * m, r1 = (size_t)B * n;
+        GsSoftmaxArgs d;
+        d.scores = scores; d.bin = bin; d.B = B; d.M = m; d.N = n; d.out = la;
+        d.row_lse = ST; d.col_lse = ST + r0;
+        d.row_best = ST + r0 + r1; d.row_arg = reinterpret_cast<int*>(ST + 2 * r0 + r1);
+        d.col_best = ST + 3 * r0 + r1; d.col_arg = reinterpret_cast<int*>(ST + 3 * r0 + 2 * r1);
+        launch_gs_double_softmax(d, s);
+        AssignArgs a;
+        a.B = B; a.M = m; a.N = n; a.threshold = conf->filter_threshold;
+        a.row_best = d.row_best; a.row_arg = d.row_arg; a.col_best = d.col_best; a.col_arg = d.col_arg;
+        a.m0 = reinterpret_cast<long long*>(mt0); a.m1 = reinterpret_cast<long long*>(mt1); a.ms0 = sc0; a.ms1 = sc1;
+        launch_assign_filter(a, s);
+    };
+
+    float* MD = QKV;
+    {
+        ProfScope ps(h, s, "gs.match");
+        Opt o;
+        if (!f16) { o.c32 = MD; o.ldc32 = 256; }
+        linear(h->gs_final, T, XA, 256, nullptr, 0, MD, 256, o);
+        sim_gemm(MD, M, N, SIM);
+        assign(SIM, h->gs_bin, M, N, log_assignment, matches0, matches1, mscores0, mscores1);
+    }
+    if (lines) {
+        ProfScope ps(h, s, "gs.line_match");
+        float* JS = h->buf("gs.js", (size_t)B * 4 * n0 * n1);
+        float* RAW = raw_line_scores ? raw_line_scores : h->buf("gs.raw", (size_t)B * n0 * n1);
+        if (!JS || !RAW) return fail(MG_ERR_HIP, "workspace allocation failed");
+        Opt o;
+        if (!f16) { o.c32 = MD; o.ldc32 = 256; }
+        linear(h->gs_final_line, T, XA, 256, nullptr, 0, MD, 256, o);  // all tokens; only the leading 2*n rows of a pair are used
+        sim_gemm(MD, 2 * (size_t)n0, 2 * (size_t)n1, JS);
+        launch_gs_line_scores(JS, reinterpret_cast<const long long*>(junc_idx0), reinterpret_cast<const long long*>(junc_idx1), B, n0, n1, RAW, s);
+        assign(RAW, h->gs_line_bin, n0, n1, line_log_assignment, line_matches0, line_matches1, line_mscores0, line_mscores1);
     }
     HIPCHK(hipGetLastError());
     return 0;

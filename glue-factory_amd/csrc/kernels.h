@@ -235,3 +235,34 @@ struct NnArgs {
     float* la = nullptr;       // optional (B,M+1,N+1)
 };
 void launch_nn_match(const NnArgs& a, hipStream_t s);
+
+// ---- gs_misc.hip : GlueStick line side -----------------------------------------------------------
+struct GsLineArgs {
+    int B = 0, M = 0, N = 0, n0 = 0, n1 = 0;
+    const long long* idx0 = nullptr;  // (B, n0, 2) junction index of every line endpoint (into the keypoints of image 0)
+    const long long* idx1 = nullptr;
+    const void* x = nullptr;          // token rows as the GEMMs read them: fp32 (f32 mode) or SH8 (f16x3), 256 channels
+    const void* enc = nullptr;        // endpoint encodings, same storage, rows = image-0 endpoints then image-1 endpoints
+    void* msg = nullptr;              // out: (E, 768) message rows, same storage
+    const float* upd = nullptr;       // (E, 256) fp32 endpoint updates (scatter input)
+    float* x32 = nullptr;             // fp32 residual stream, updated in place
+    void* xs = nullptr;               // SH8 copy, refreshed for touched rows (nullptr in f32 mode)
+};
+void launch_gs_lenc_input(const float* l0, const float* l1, const float* s0, const float* s1, const float* size0, const float* size1, int B, int n0,
+                          int n1, float* out, hipStream_t s);
+void launch_gs_gather_msg(const GsLineArgs& a, hipStream_t s);
+void launch_gs_scatter_mean(const GsLineArgs& a, hipStream_t s);
+struct GsSoftmaxArgs {
+    const float* scores = nullptr;  // (B,M,N)
+    float bin = 1.f;
+    int B = 0, M = 0, N = 0;
+    float* row_lse = nullptr;       // (B,M) workspace
+    float* col_lse = nullptr;       // (B,N)
+    float* out = nullptr;           // optional (B,M+1,N+1)
+    float* row_best = nullptr;      // (B,M)
+    int* row_arg = nullptr;
+    float* col_best = nullptr;      // (B,N)
+    int* col_arg = nullptr;
+};
+void launch_gs_double_softmax(const GsSoftmaxArgs& a, hipStream_t s);
+void launch_gs_line_scores(const float* J, const long long* idx0, const long long* idx1, int B, int n0, int n1, float* raw, hipStream_t s);

@@ -20,7 +20,7 @@ MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN = 0, 1, 2
 # every symbol include/matchglue.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_precision", "mg_set_weight", "mg_weights_ready",
-    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_sg_forward", "mg_nn_forward", "mg_debug_request", "mg_debug_read",
+    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_sg_forward", "mg_gs_forward", "mg_nn_forward", "mg_debug_request", "mg_debug_read",
     "mg_profile_enable", "mg_profile_read", "mg_test_linear",
 ]
 
@@ -42,6 +42,10 @@ class LgConf(Structure):
 
 class SgConf(Structure):
     _fields_ = [("n_layers", c_int32), ("sinkhorn_iterations", c_int32), ("filter_threshold", c_float)]
+
+
+class GsConf(Structure):
+    _fields_ = [("n_layers", c_int32), ("filter_threshold", c_float)]
 
 
 class NnConf(Structure):
@@ -75,6 +79,7 @@ def lib():
     L.mg_sp_sample.argtypes = [c_void_p, POINTER(SpConf), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.mg_lg_forward.argtypes = [c_void_p, POINTER(LgConf)] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 8
     L.mg_sg_forward.argtypes = [c_void_p, POINTER(SgConf)] + [c_void_p] * 8 + [c_int] * 3 + [c_void_p] * 7
+    L.mg_gs_forward.argtypes = [c_void_p, POINTER(GsConf)] + [c_void_p] * 14 + [c_int] * 5 + [c_void_p] * 12
     L.mg_nn_forward.argtypes = [c_void_p, POINTER(NnConf), c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 7
     L.mg_debug_request.argtypes = [c_void_p, c_char_p]
     L.mg_debug_read.argtypes = [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]
@@ -230,6 +235,41 @@ class Engine:
         _check(lib().mg_sg_forward(self._h, ctypes.byref(conf), _ptr(k0), _ptr(k1), _ptr(d0), _ptr(d1), _ptr(sc0), _ptr(sc1), _ptr(s0),
                                    _ptr(s1), B, M, N, _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1), _ptr(la), _ptr(cost), _stream(dev)))
         return m0, m1, ms0, ms1, la, cost
+
+    # -- GlueStick -------------------------------------------------------------------------------
+    def gs_forward(self, conf, k0, k1, d0, d1, sc0, sc1, size0, size1, lines0, lines1, idx0, idx1, ls0, ls1, want_log_assignment=True):
+        dev = self.device
+        k0, k1, d0, d1, sc0, sc1 = (_f32(t, dev) for t in (k0, k1, d0, d1, sc0, sc1))
+        B, M, _ = k0.shape
+        N = k1.shape[1]
+        n0, n1 = lines0.shape[1], lines1.shape[1]
+        if d0.shape != (B, M, 256) or d1.shape != (B, N, 256):
+            raise RuntimeError(f"descriptors must be (B,K,256); got {tuple(d0.shape)} / {tuple(d1.shape)}")
+        s0 = _f32(size0, dev).reshape(-1, 2).expand(B, 2).contiguous()
+        s1 = _f32(size1, dev).reshape(-1, 2).expand(B, 2).contiguous()
+        m0 = torch.empty(B, M, dtype=torch.int64, device=dev)
+        m1 = torch.empty(B, N, dtype=torch.int64, device=dev)
+        ms0 = torch.empty(B, M, device=dev)
+        ms1 = torch.empty(B, N, device=dev)
+        la = torch.empty(B, M + 1, N + 1, device=dev) if want_log_assignment else None
+        lines = n0 > 0 and n1 > 0
+        L0 = L1 = I0 = I1 = S0 = S1 = lm0 = lm1 = lms0 = lms1 = lla = raw = None
+        if lines:
+            L0, L1, S0, S1 = _f32(lines0, dev), _f32(lines1, dev), _f32(ls0, dev), _f32(ls1, dev)
+            I0 = idx0.to(device=dev, dtype=torch.int64).contiguous()
+            I1 = idx1.to(device=dev, dtype=torch.int64).contiguous()
+            if L0.shape != (B, n0, 2, 2) or L1.shape != (B, n1, 2, 2) or I0.shape != (B, n0, 2) or I1.shape != (B, n1, 2):
+                raise RuntimeError("lines must be (B,n,2,2) and lines_junc_idx (B,n,2)")
+            lm0 = torch.empty(B, n0, dtype=torch.int64, device=dev)
+            lm1 = torch.empty(B, n1, dtype=torch.int64, device=dev)
+            lms0 = torch.empty(B, n0, device=dev)
+            lms1 = torch.empty(B, n1, device=dev)
+            lla = torch.empty(B, n0 + 1, n1 + 1, device=dev)
+            raw = torch.empty(B, n0, n1, device=dev)
+        _check(lib().mg_gs_forward(self._h, ctypes.byref(conf), _ptr(k0), _ptr(k1), _ptr(d0), _ptr(d1), _ptr(sc0), _ptr(sc1), _ptr(s0), _ptr(s1),
+                                   _ptr(L0), _ptr(L1), _ptr(I0), _ptr(I1), _ptr(S0), _ptr(S1), B, M, N, n0, n1, _ptr(m0), _ptr(m1), _ptr(ms0),
+                                   _ptr(ms1), _ptr(la), _ptr(lm0), _ptr(lm1), _ptr(lms0), _ptr(lms1), _ptr(lla), _ptr(raw), _stream(dev)))
+        return (m0, m1, ms0, ms1, la), (lm0, lm1, lms0, lms1, lla, raw)
 
     # -- nearest-neighbour matcher ----------------------------------------------------------------
     def nn_forward(self, conf, d0, d1, want_similarity=True, want_log_assignment=True):

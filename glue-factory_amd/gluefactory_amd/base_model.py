@@ -141,7 +141,7 @@ class BaseModel(nn.Module):
 class NativeModel(BaseModel):
     """A BaseModel whose arithmetic runs in libmatchglue; holds the weights and the native handle."""
 
-    which = 0  # 0 SuperPoint, 1 LightGlue (mg_set_weight `which`)
+    which = 0  # 0 SuperPoint, 1 LightGlue, 2 SuperGlue, 3 GlueStick (mg_set_weight `which`)
 
     # weights -------------------------------------------------------------------------------------
     def _init_weights(self, conf):

@@ -19,6 +19,8 @@ _ALIASES = {
     "gluefactory.models.matchers.lightglue": "gluefactory_amd.lightglue",
     "gluefactory_nonfree.superglue": "gluefactory_amd.superglue",
     "matchers.nearest_neighbor_matcher": "gluefactory_amd.nearest_neighbor_matcher",
+    "matchers.gluestick": "gluefactory_amd.gluestick",
+    "gluefactory.models.matchers.gluestick": "gluefactory_amd.gluestick",
     "gluefactory.models.matchers.nearest_neighbor_matcher": "gluefactory_amd.nearest_neighbor_matcher",
 }
 

@@ -77,7 +77,7 @@ int mg_set_precision(mg_handle h, int mode);
  * Upload one tensor of a reference state_dict, addressed by its reference key name
  * ("conv1a.weight", "backbone.0.0.bn.running_var", "transformers.3.self_attn.Wqkv.weight", ...).
  * `data` is a HOST pointer to contiguous fp32 in the reference's own layout (OIHW / [out][in]);
- * the library re-tiles it for the kernels.  `which` selects the model: 0 = SuperPoint, 1 = LightGlue, 2 = SuperGlue.
+ * the library re-tiles it for the kernels.  `which` selects the model: 0 = SuperPoint, 1 = LightGlue, 2 = SuperGlue, 3 = GlueStick.
  * mg_weights_ready() re-tiles and uploads; it returns 0 once every tensor the model needs has
  * arrived.  `variant_or_layers` is the mg_sp_variant for which == 0 and n_layers for which == 1. */
 int mg_set_weight(mg_handle h, int which, const char* key, const float* data, const int64_t* shape, int ndim);
@@ -137,6 +137,28 @@ int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const
                   const float* size0, const float* size1, int B, int M, int N, int64_t* matches0,
                   int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment,
                   float* sinkhorn_cost, void* stream);
+
+/* -- GlueStick ------------------------------------------------------------------
+ * gluefactory/models/matchers/gluestick.py:136-312: SuperGlue-style GNN over keypoints whose leading entries are the
+ * line junctions, a line layer after every self layer (per-endpoint MLP, mean per junction), double log-softmax
+ * assignment with a dustbin for points and for lines.  Released shape only: input_dim = descriptor_dim = 256,
+ * keypoint_encoder [32,64,128,256], num_line_iterations 1, line_attention off, no intermediate supervision.
+ * Weights: mg_set_weight(h, 3, key, ...) with the reference key names, then mg_weights_ready(h, 3, n_layers).
+ * lines0/1 (B,n,2,2) endpoint pixel coordinates; junc_idx0/1 (B,n,2) int64 keypoint index of every endpoint, all
+ * < 2*n (the reference slices the junctions off the front of the keypoint list, :262-263); line_scores0/1 (B,n).
+ * With n0 == 0 or n1 == 0 the line arguments may be NULL and no line output is written.
+ * log_assignment (B,M+1,N+1), line_log_assignment (B,n0+1,n1+1), raw_line_scores (B,n0,n1) are optional. */
+typedef struct mg_gs_conf {
+    int32_t n_layers;            /* 18 */
+    float filter_threshold;
+} mg_gs_conf;
+int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const float* kpts1, const float* desc0,
+                  const float* desc1, const float* scores0, const float* scores1, const float* size0, const float* size1,
+                  const float* lines0, const float* lines1, const int64_t* junc_idx0, const int64_t* junc_idx1,
+                  const float* line_scores0, const float* line_scores1, int B, int M, int N, int n0, int n1,
+                  int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment,
+                  int64_t* line_matches0, int64_t* line_matches1, float* line_mscores0, float* line_mscores1,
+                  float* line_log_assignment, float* raw_line_scores, void* stream);
 
 /* -- nearest-neighbour matcher ------------------------------------------------
  * gluefactory/models/matchers/nearest_neighbor_matcher.py:51-72: sim = desc0 . desc1^T, best (and second best for

@@ -31,7 +31,7 @@ def test_library_exports_every_declared_symbol(libpath):
     lib = ctypes.CDLL(libpath)
     for sym in declared_symbols():
         assert hasattr(lib, sym), sym
-    assert lib.mg_abi_version() == 4
+    assert lib.mg_abi_version() == 5
 
 
 def test_struct_layouts_match_header():
