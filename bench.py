@@ -72,6 +72,8 @@ def algorithmic_flops(B):
         "sg.gemm.qkv": lin(256, 768), "sg.gemm.mlp0": lin(512, 512), "sg.gemm.mlp3": lin(512, 256),
         "sg.gemm.final_proj": lin(256, 256), "sg.gemm.cost": 2.0 * B * K * K * 256,
         "sg.attn.self": 2 * (2.0 * 4 * K * K * 64) * 2 * B, "sg.attn.cross": 2 * (2.0 * 4 * K * K * 64) * 2 * B,
+        "gs.gemm.qkv": lin(256, 768), "gs.gemm.mlp": lin(512, 512) + lin(512, 256),
+        "gs.attn.self": 2 * (2.0 * 4 * K * K * 64) * 2 * B, "gs.attn.cross": 2 * (2.0 * 4 * K * K * 64) * 2 * B,
     }
     return f
 
@@ -85,6 +87,8 @@ def cpu_baseline(pairs=4, matcher="lightglue"):
     cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(cores)
     W_sp = O.make_sp_weights(0)
+    if matcher == "gluestick":
+        return None  # secondary workload: its line inputs are built from the GPU run's keypoints
     W_lg = O.make_lg_weights(7, final_gain=8.0, match_bias=2.0) if matcher == "lightglue" else O.make_sg_weights(9)
     im = synthetic_images(2 * pairs, 123)
     size = torch.tensor([[float(W), float(H)]])
@@ -116,8 +120,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--precision", default="f16x3", choices=["f32", "f16x3"],
                     help="f32: fp32-input MFMA; f16x3: split-fp16 operands on the f16 MFMA (default, fp32-class accuracy)")
-    ap.add_argument("--matcher", default="lightglue", choices=["lightglue", "superglue"],
-                    help="lightglue: the north-star workload (configs[1]); superglue: configs[3] (use --kpts 2048)")
+    ap.add_argument("--matcher", default="lightglue", choices=["lightglue", "superglue", "gluestick"],
+                    help="lightglue: the north-star workload (configs[1]); superglue: configs[3] (use --kpts 2048); "
+                         "gluestick: configs[4] with synthetic line segments between detected keypoints (LSD is a CPU dependency)")
+    ap.add_argument("--lines", type=int, default=250, help="line segments per image (gluestick)")
     ap.add_argument("--kpts", type=int, default=K, help="keypoints per image")
     args = ap.parse_args()
     K = args.kpts
@@ -142,18 +148,33 @@ def main():
         "extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": K, "nms_radius": 3,
                       "detection_threshold": 0.0, "remove_borders": 4, "force_num_keypoints": True, "sync_free": True,
                       "precision": args.precision},
-        "matcher": ({"name": "matchers.lightglue", "filter_threshold": 0.1, "precision": args.precision}
-                    if args.matcher == "lightglue" else
-                    {"name": "gluefactory_nonfree.superglue", "filter_threshold": 0.2, "precision": args.precision,
-                     "return_log_assignment": False}),
+        "matcher": {"lightglue": {"name": "matchers.lightglue", "filter_threshold": 0.1, "precision": args.precision},
+                    "superglue": {"name": "gluefactory_nonfree.superglue", "filter_threshold": 0.2, "precision": args.precision,
+                                  "return_log_assignment": False},
+                    "gluestick": {"name": "matchers.gluestick", "filter_threshold": 0.2, "precision": args.precision,
+                                  "return_log_assignment": False}}[args.matcher],
     }).eval()
     pipe.extractor.load_state_dict(O.make_sp_weights(0))
-    pipe.matcher.load_state_dict(O.make_lg_weights(7, final_gain=8.0, match_bias=2.0) if args.matcher == "lightglue"
-                                 else O.make_sg_weights(9))
+    pipe.matcher.load_state_dict({"lightglue": lambda: O.make_lg_weights(7, final_gain=8.0, match_bias=2.0),
+                                  "superglue": lambda: O.make_sg_weights(9), "gluestick": lambda: O.make_gs_weights(4)}[args.matcher]())
 
     im = synthetic_images(2 * B, 1000 + rank).to(dev)
     size = torch.tensor([[float(W), float(H)]] * B, device=dev)
     data = {"view0": {"image": im[:B], "image_size": size}, "view1": {"image": im[B:], "image_size": size}}
+
+    if args.matcher == "gluestick":
+        # wireframe-style line inputs: the first 2n detected keypoints of every image act as junctions, n segments
+        # join random pairs of them (same images every step -> same keypoints, so the segments are built once)
+        n = args.lines
+        g = torch.Generator().manual_seed(5)
+        kp = pipe.extractor({"image": im, "image_size": torch.cat([size, size], 0)})["keypoints"]
+        for side, kps in (("0", kp[:B]), ("1", kp[B:])):
+            idx = torch.randint(0, 2 * n, (B, n, 2), generator=g)
+            idx[:, :, 1] = torch.where(idx[:, :, 1] == idx[:, :, 0], (idx[:, :, 1] + 1) % (2 * n), idx[:, :, 1])
+            idx = idx.to(dev)
+            data["lines_junc_idx" + side] = idx
+            data["lines" + side] = torch.gather(kps, 1, idx.reshape(B, 2 * n)[..., None].expand(-1, -1, 2)).reshape(B, n, 2, 2)
+            data["line_scores" + side] = torch.rand(B, n, generator=g).to(dev)
 
     def step():
         pred = pipe(data)
@@ -235,7 +256,10 @@ def main():
             "data": "synthetic",
             "config": {"workload": (f"SuperPoint + LightGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[1])"
                                     if args.matcher == "lightglue" else
-                                    f"SuperPoint + SuperGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[3])"),
+                                    f"SuperPoint + SuperGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[3])"
+                                    if args.matcher == "superglue" else
+                                    f"SuperPoint + GlueStick, {W}x{H}, {K} kpts + {args.lines} synthetic segments, batch={B} pairs per GPU "
+                                    "(BASELINE.json configs[4]; LSD itself is a CPU dependency and not timed)"),
                        "pairs_per_gpu": B, "global_pairs": B * world, "parallelism": f"dp{world}", "matches_per_step_rank0": nvalid,
                        "arithmetic": ("fp32 storage, fp32-input MFMA, fp32 accumulate" if args.precision == "f32" else
                                       "fp32-equivalent split-fp16 storage (hi+lo), f16 MFMA x3 products, fp32 accumulate")},
@@ -249,9 +273,21 @@ def main():
                          "kernel_time_share": round(prof[dom][0] / total_ms, 4)},
             "kernels": kernels,
         }
+        att = [k for k in prof if ".attn." in k and k in flops]
+        if att:  # the attention contractions (QK^T + PV) on their own: north_star asks for their MFMA utilisation
+            a_ms = sum(prof[k][0] for k in att)
+            a_fl = sum(flops[k] * prof[k][1] for k in att)
+            a_tf = a_fl / (a_ms * 1e-3) / 1e12
+            mult = 1 if args.precision == "f32" else 3
+            res["attention_mfma"] = {"kernels": sorted(att), "achieved_algorithmic": round(a_tf, 2), "executed": round(a_tf * mult, 2),
+                                     "peak": PEAK[args.precision], "unit": "TFLOP/s", "executed_frac": round(a_tf * mult / PEAK[args.precision], 4),
+                                     "executed_frac_of_sustained": (round(a_tf * mult / SUSTAINED[args.precision], 4) if SUSTAINED[args.precision] else None),
+                                     "ms_per_step": round(a_ms / args.steps, 4)}
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle on a bounded sample (10-30 s)")
-            res["cpu_baseline"] = cpu_baseline(matcher=args.matcher)
+            cb = cpu_baseline(matcher=args.matcher)
+            if cb is not None:
+                res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)
     if world > 1:
         dist.destroy_process_group()
