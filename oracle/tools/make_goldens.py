@@ -318,6 +318,50 @@ def gold_gluestick():
     save("gluestick", **arrs)
 
 
+def export_fixture(n_pairs=4, K=12, seed=41):
+    """Deterministic fake loader + model for the export test: every pair detects a different number of keypoints."""
+    g = torch.Generator().manual_seed(seed)
+    pairs = []
+    for i in range(n_pairs):
+        n0, n1 = K - (i % 3), K - ((i + 1) % 4)
+        item = {}
+        for sfx, n in (("0", n0), ("1", n1)):
+            item["keypoints" + sfx] = torch.rand(n, 2, generator=g) * 100
+            item["keypoint_scores" + sfx] = torch.rand(n, generator=g).sort(descending=True).values * 0.9 + 0.05
+            item["descriptors" + sfx] = torch.randn(n, 8, generator=g)
+        m0 = torch.randint(-1, n1, (n0,), generator=g)
+        item["matches0"], item["matching_scores0"] = m0, (m0 > -1).float() * 0.5
+        m1 = torch.randint(-1, n0, (n1,), generator=g)
+        item["matches1"], item["matching_scores1"] = m1, (m1 > -1).float() * 0.5
+        scales0, scales1 = torch.rand(2, generator=g) + 0.5, torch.rand(2, generator=g) + 0.5
+        pairs.append((f"seq{i // 2}/pair{i}.ppm", item, scales0, scales1))
+    return pairs
+
+
+def gold_export():
+    """gluefactory/utils/export_predictions.py run as is (batch 1, as it only supports) on the fixture; h5py is the
+    in-memory stand-in of oracle/tools/_shim."""
+    import h5py
+    from gluefactory.utils.export_predictions import export_predictions
+
+    pairs = export_fixture()
+    loader = [{"name": [name], "idx": torch.tensor([i]), "view0": {"scales": s0[None]}, "view1": {"scales": s1[None]}}
+              for i, (name, _, s0, s1) in enumerate(pairs)]
+
+    class Model(torch.nn.Module):
+        def forward(self, data):
+            return {k: v[None] for k, v in pairs[int(data["idx"][0])][1].items()}
+
+    arrs = {}
+    for half in (False, True):
+        out = f"/tmp/export_gold_{int(half)}.h5"
+        export_predictions(loader, Model(), out, as_half=half)
+        for name, grp in h5py.FILES[out].items():
+            for k, ds in grp.items():
+                arrs[f"half{int(half)}|{name}|{k}"] = ds.data
+    save("export_h5", **arrs)
+
+
 def gold_nn():
     """gluefactory/models/matchers/nearest_neighbor_matcher.py run as is; descriptors with clear margins
     (noisy permuted copies) so that the arg-maxes do not hinge on the last bit of a dot product."""
@@ -395,5 +439,6 @@ if __name__ == "__main__":
     gold_lightglue()
     gold_superglue()
     gold_nn()
+    gold_export()
     gold_gluestick()
     gold_two_view(boat)
