@@ -22,6 +22,10 @@ namespace {
 
 constexpr int CT = 512;  // threads per workgroup of the 8-wave arrangements
 
+// Phase ablations used for the numbers in DESIGN.md: compile this file with -DCONV_ABL=<n> into a second library and
+// run bench.py with MG_LIB_PATH pointing at it (same box, same clocks).  7 = epilogue without its stores, 9 = conv1a
+// produced for the first chunk only, 10 = no weight re-staging, 11 = no MFMA phase.  Results are wrong by design.
+
 // Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Re-number them so that one XCD works
 // through a CONTIGUOUS run of (image, tile, cout slice) items with the slice index fastest: the cout slices of a
 // pixel tile (which read the same input tile) and spatially adjacent tiles (which share halo rows / columns) are
@@ -106,11 +110,8 @@ __device__ __forceinline__ void half_swap8(float (&v)[16]) {
           "+v"(v[10]), "+v"(v[11]), "+v"(v[12]), "+v"(v[13]), "+v"(v[14]), "+v"(v[15]));
 }
 
-#if defined(CONV_ABL) && CONV_ABL == 8
-#define STORE_OUT(ptr, val) __builtin_nontemporal_store((val), (ptr))
-#else
+// (non-temporal stores were tried here: no measurable difference)
 #define STORE_OUT(ptr, val) (*(ptr) = (val))
-#endif
 // Hot epilogue (every layer of the MagicLeap layout): ReLU on accumulators that were initialised with the bias,
 // optional 2x2 max-pool inside the lane quad, SH8 output.  32-bit offsets inside the image, no per-channel loads.
 template <bool POOL>
