@@ -80,14 +80,16 @@ constexpr int COUNT_STRIDE = 32;  // ints between per-image candidate counters (
 // Separable (2R+1)^2 max-pool over a TxT LDS tile (row stride TP).  Each thread produces 4 adjacent
 // outputs from a 4+2R register window, so a pass costs (4+2R)/4 LDS reads per element instead of
 // 2R+1.  Indices are clamped into the tile: a duplicated edge value cannot change a maximum.
-template <int R, int T, int TP>
-__device__ __forceinline__ void pool_pass(const float* src, float* tmp, float* dst) {
+// `load(offset)` supplies the pooled quantity on the fly and `store(offset, pooled)` consumes the result, so the
+// element-wise steps of simple_nms ride on the pooling passes instead of being LDS round trips of their own.
+template <int R, int T, int TP, class Load, class Store>
+__device__ __forceinline__ void pool_pass(Load load, float* tmp, Store store) {
     constexpr int G = (T + 3) / 4;  // groups of 4 along the pooled axis
     for (int i = threadIdx.x; i < T * G; i += NMS_THREADS) {
         const int y = i / G, x0 = (i - y * G) * 4;
         float w[4 + 2 * R];
 #pragma unroll
-        for (int k = 0; k < 4 + 2 * R; ++k) w[k] = src[y * TP + min(max(x0 + k - R, 0), T - 1)];
+        for (int k = 0; k < 4 + 2 * R; ++k) w[k] = load(y * TP + min(max(x0 + k - R, 0), T - 1));
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             float m = w[j];
@@ -107,7 +109,7 @@ __device__ __forceinline__ void pool_pass(const float* src, float* tmp, float* d
             float m = w[j];
 #pragma unroll
             for (int k = 1; k <= 2 * R; ++k) m = fmaxf(m, w[j + k]);
-            if (y0 + j < T) dst[(y0 + j) * TP + x] = m;
+            if (y0 + j < T) store((y0 + j) * TP + x, m);
         }
     }
     __syncthreads();
@@ -117,7 +119,6 @@ template <int R>
 __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const DetectArgs p) {
     constexpr int halo = 5 * R, T = NMS_TILE + 2 * halo, TP = (T + 3) / 4 * 4 + 1, n = T * T;
     __shared__ float s_s[T * TP];
-    __shared__ float s_a[T * TP];
     __shared__ float s_t[(T * TP > 2048) ? T * TP : 2048];  // also the 1024-entry u64 candidate staging
     __shared__ unsigned char s_keep[T * TP];
     __shared__ unsigned char s_supp[T * TP];
@@ -134,34 +135,15 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const DetectArgs p) {
     }
     __syncthreads();
     if (R > 0) {
-        pool_pass<R, T, TP>(s_s, s_t, s_a);
-        for (int i = threadIdx.x; i < n; i += NMS_THREADS) {
-            const int y = i / T, o = y * TP + (i - y * T);
-            s_keep[o] = (s_s[o] != NEG) && (s_s[o] == s_a[o]);
-        }
-        __syncthreads();
+        // max_mask = scores == max_pool(scores)                                     (superpoint.py:71)
+        pool_pass<R, T, TP>([&](int o) { return s_s[o]; }, s_t, [&](int o, float m) { s_keep[o] = (s_s[o] != NEG) && (s_s[o] == m); });
         for (int it = 0; it < 2; ++it) {
-            for (int i = threadIdx.x; i < n; i += NMS_THREADS) {
-                const int y = i / T, o = y * TP + (i - y * T);
-                s_a[o] = s_keep[o] ? 1.f : 0.f;
-            }
-            __syncthreads();
-            pool_pass<R, T, TP>(s_a, s_t, s_a);
-            for (int i = threadIdx.x; i < n; i += NMS_THREADS) {
-                const int y = i / T, o = y * TP + (i - y * T);
-                const unsigned char sp = s_a[o] > 0.f;
-                s_supp[o] = sp;
-                s_a[o] = (s_s[o] == NEG) ? NEG : (sp ? 0.f : s_s[o]);
-            }
-            __syncthreads();
-            pool_pass<R, T, TP>(s_a, s_t, s_a);
-            for (int i = threadIdx.x; i < n; i += NMS_THREADS) {
-                const int y = i / T, o = y * TP + (i - y * T);
-                if (s_s[o] == NEG) continue;
-                const float rest = s_supp[o] ? 0.f : s_s[o];
-                if ((rest == s_a[o]) && !s_supp[o]) s_keep[o] = 1;
-            }
-            __syncthreads();
+            // supp_mask = max_pool(max_mask.float()) > 0                             (:73)
+            pool_pass<R, T, TP>([&](int o) { return s_keep[o] ? 1.f : 0.f; }, s_t, [&](int o, float m) { s_supp[o] = m > 0.f; });
+            // supp_scores = where(supp_mask, 0, scores); new_max = supp_scores == max_pool(supp_scores);
+            // max_mask |= new_max & ~supp_mask                                        (:74-76)
+            pool_pass<R, T, TP>([&](int o) { return s_s[o] == NEG ? NEG : (s_supp[o] ? 0.f : s_s[o]); }, s_t,
+                                [&](int o, float m) { if (s_s[o] != NEG && !s_supp[o] && s_s[o] == m) s_keep[o] = 1; });
         }
     } else {
         for (int i = threadIdx.x; i < T * TP; i += NMS_THREADS) s_keep[i] = 1;  // radius 0: every pixel is its own maximum
