@@ -1071,6 +1071,7 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         float* cbase = ST + 4 * T0;
         a.col_mx = cbase; a.col_ls = cbase + T1; a.col_best = cbase + 2 * T1;
         a.col_arg = reinterpret_cast<int*>(cbase + 3 * T1);
+        a.ls0 = ST + 4 * T; a.ls1 = a.ls0 + T0; a.lsn0 = ST + 5 * T; a.lsn1 = a.lsn0 + T0;
         a.log_assignment = log_assignment;
         a.m0 = reinterpret_cast<long long*>(matches0); a.m1 = reinterpret_cast<long long*>(matches1);
         a.ms0 = mscores0; a.ms1 = mscores1;

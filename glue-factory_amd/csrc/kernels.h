@@ -179,10 +179,14 @@ void launch_matchability(const float* x, long long rows, const float* w, float b
 struct AssignArgs {
     const float* sim = nullptr;  // (B,M,N)
     const float* z0 = nullptr;   // (B*M) matchability logits of image 0
-    const float* z1 = nullptr;   // (B*N)
+    const float* z1 = nullptr;   // (B*N), directly behind z0
     int B = 0, M = 0, N = 0;
     float threshold = 0.f;
     // workspace
+    float* ls0 = nullptr;        // (B*M + B*N) log sigmoid(z), image 0 then image 1 (ls1 = ls0 + B*M)
+    float* ls1 = nullptr;
+    float* lsn0 = nullptr;       // (B*M + B*N) log sigmoid(-z)
+    float* lsn1 = nullptr;
     float* row_mx = nullptr;     // (B,M) max_j sim
     float* row_ls = nullptr;     // (B,M) log sum_j exp(sim - max)
     float* col_mx = nullptr;     // (B,N)

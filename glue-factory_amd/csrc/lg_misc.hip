@@ -133,25 +133,52 @@ __global__ __launch_bounds__(256) void assign_row_stats(const AssignArgs p) {
     if (lane == 0) { p.row_mx[row] = m; p.row_ls[row] = logf(acc); }
 }
 
-// Column statistics: 64 columns per block, 4 row groups, online max/sum then an LDS combine.
-__global__ __launch_bounds__(256) void assign_col_stats(const AssignArgs p) {
-    __shared__ float s_m[4][64], s_l[4][64];
-    const int b = blockIdx.y, c = blockIdx.x * 64 + (threadIdx.x & 63), g = threadIdx.x >> 6;
+// log sigmoid(z) and log sigmoid(-z) of every matchability logit, once (the assembly kernels below would otherwise
+// evaluate them M*N times)
+__global__ __launch_bounds__(256) void assign_prep(const float* __restrict__ z, long long n, float* __restrict__ ls, float* __restrict__ lsn) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    ls[i] = log_sigmoid(z[i]);
+    lsn[i] = log_sigmoid(-z[i]);
+}
+
+constexpr int ACW = 8, ACB = 4;  // column sweeps: waves per block (interleaved rows), independent loads per batch
+
+// Column statistics: 64 columns per block, online max/sum per lane then an LDS combine.
+__global__ __launch_bounds__(64 * ACW) void assign_col_stats(const AssignArgs p) {
+    __shared__ float s_m[ACW][64], s_l[ACW][64];
+    const int b = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, g = threadIdx.x >> 6;
     const float* s = p.sim + (long long)b * p.M * p.N;
     float m = -__builtin_inff(), l = 0.f;
     if (c < p.N)
-        for (int i = g; i < p.M; i += 4) {
-            const float v = s[(long long)i * p.N + c];
-            if (v > m) { l = l * expf(m - v) + 1.f; m = v; } else { l += expf(v - m); }
+        for (int i0 = g; i0 < p.M; i0 += ACW * ACB) {
+            float v[ACB];
+#pragma unroll
+            for (int k = 0; k < ACB; ++k) {
+                const int i = i0 + ACW * k;
+                v[k] = i < p.M ? s[(long long)i * p.N + c] : -__builtin_inff();
+            }
+            float bm = v[0];
+#pragma unroll
+            for (int k = 1; k < ACB; ++k) bm = fmaxf(bm, v[k]);
+            const float nm = fmaxf(m, bm);
+            float acc = 0.f;
+#pragma unroll
+            for (int k = 0; k < ACB; ++k) acc += expf(v[k] - nm);
+            l = l * expf(m - nm) + acc;
+            m = nm;
         }
-    s_m[g][threadIdx.x & 63] = m;
-    s_l[g][threadIdx.x & 63] = l;
+    s_m[g][cl] = m;
+    s_l[g][cl] = l;
     __syncthreads();
     if (g == 0 && c < p.N) {
-        float mm = fmaxf(fmaxf(s_m[0][threadIdx.x], s_m[1][threadIdx.x]), fmaxf(s_m[2][threadIdx.x], s_m[3][threadIdx.x]));
+        float mm = s_m[0][cl];
+#pragma unroll
+        for (int k = 1; k < ACW; ++k) mm = fmaxf(mm, s_m[k][cl]);
         float ll = 0.f;
-        for (int k = 0; k < 4; ++k)
-            if (s_l[k][threadIdx.x] > 0.f) ll += s_l[k][threadIdx.x] * expf(s_m[k][threadIdx.x] - mm);
+#pragma unroll
+        for (int k = 0; k < ACW; ++k)
+            if (s_l[k][cl] > 0.f) ll += s_l[k][cl] * expf(s_m[k][cl] - mm);
         p.col_mx[(long long)b * p.N + c] = mm;
         p.col_ls[(long long)b * p.N + c] = logf(ll);
     }
@@ -174,20 +201,20 @@ __global__ __launch_bounds__(256) void assign_rows(const AssignArgs p) {
     float* la = p.log_assignment ? p.log_assignment + row * (p.N + 1) : nullptr;
     if (i == p.M) {  // last row: unmatched bin of image 1
         if (la) {
-            for (int j = lane; j < p.N; j += 64) la[j] = log_sigmoid(-p.z1[(long long)b * p.N + j]);
+            for (int j = lane; j < p.N; j += 64) la[j] = p.lsn1[(long long)b * p.N + j];
             if (lane == 0) la[p.N] = 0.f;
         }
         return;
     }
     const long long r = (long long)b * p.M + i;
     const float* s = p.sim + r * p.N;
-    const float rmx = p.row_mx[r], rls = p.row_ls[r], z0 = p.z0[r];
-    const float ls0 = log_sigmoid(z0);
+    const float rmx = p.row_mx[r], rls = p.row_ls[r];
+    const float ls0 = p.ls0[r];
     float best = -__builtin_inff();
     int arg = 0x7fffffff;
     for (int j = lane; j < p.N; j += 64) {
         const long long c = (long long)b * p.N + j;
-        const float cert = __fadd_rn(ls0, log_sigmoid(p.z1[c]));
+        const float cert = __fadd_rn(ls0, p.ls1[c]);
         const float v = assign_value(s[j], rmx, rls, p.col_mx[c], p.col_ls[c], cert);
         if (la) la[j] = v;
         if (v > best) { best = v; arg = j; }
@@ -201,33 +228,44 @@ __global__ __launch_bounds__(256) void assign_rows(const AssignArgs p) {
     if (lane == 0) {
         p.row_best[r] = best;
         p.row_arg[r] = arg;
-        if (la) la[p.N] = log_sigmoid(-z0);
+        if (la) la[p.N] = p.lsn0[r];
     }
 }
 
-// Column arg-max of S: 64 columns per block, 4 row groups.
-__global__ __launch_bounds__(256) void assign_cols(const AssignArgs p) {
-    __shared__ float s_b[4][64];
-    __shared__ int s_a[4][64];
+// Column arg-max of S: 64 columns per block, interleaved rows, first maximum wins.
+__global__ __launch_bounds__(64 * ACW) void assign_cols(const AssignArgs p) {
+    __shared__ float s_b[ACW][64];
+    __shared__ int s_a[ACW][64];
     const int b = blockIdx.y, cl = threadIdx.x & 63, c = blockIdx.x * 64 + cl, g = threadIdx.x >> 6;
     const float* s = p.sim + (long long)b * p.M * p.N;
     float best = -__builtin_inff();
     int arg = 0x7fffffff;
     if (c < p.N) {
         const long long cc = (long long)b * p.N + c;
-        const float cmx = p.col_mx[cc], cls = p.col_ls[cc], ls1 = log_sigmoid(p.z1[cc]);
-        for (int i = g; i < p.M; i += 4) {
-            const long long r = (long long)b * p.M + i;
-            const float cert = __fadd_rn(log_sigmoid(p.z0[r]), ls1);
-            const float v = assign_value(s[(long long)i * p.N + c], p.row_mx[r], p.row_ls[r], cmx, cls, cert);
-            if (v > best) { best = v; arg = i; }
+        const float cmx = p.col_mx[cc], cls = p.col_ls[cc], ls1 = p.ls1[cc];
+        for (int i0 = g; i0 < p.M; i0 += ACW * ACB) {
+            float v[ACB];
+#pragma unroll
+            for (int k = 0; k < ACB; ++k) {
+                const int i = i0 + ACW * k;
+                v[k] = i < p.M ? s[(long long)i * p.N + c] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < ACB; ++k) {
+                const int i = i0 + ACW * k;
+                if (i < p.M) {
+                    const long long r = (long long)b * p.M + i;
+                    const float x = assign_value(v[k], p.row_mx[r], p.row_ls[r], cmx, cls, __fadd_rn(p.ls0[r], ls1));
+                    if (x > best) { best = x; arg = i; }
+                }
+            }
         }
     }
     s_b[g][cl] = best;
     s_a[g][cl] = arg;
     __syncthreads();
     if (g == 0 && c < p.N) {
-        for (int k = 1; k < 4; ++k)
+        for (int k = 1; k < ACW; ++k)
             if (s_b[k][cl] > best || (s_b[k][cl] == best && s_a[k][cl] < arg)) { best = s_b[k][cl]; arg = s_a[k][cl]; }
         p.col_best[(long long)b * p.N + c] = best;
         p.col_arg[(long long)b * p.N + c] = arg;
@@ -275,12 +313,13 @@ void launch_matchability(const float* x, long long rows, const float* w, float b
 }
 
 void launch_assignment(const AssignArgs& a, hipStream_t s) {
-    const long long rows = (long long)a.B * a.M;
+    const long long rows = (long long)a.B * a.M, T = (long long)a.B * (a.M + a.N);
+    hipLaunchKernelGGL(assign_prep, dim3((unsigned)((T + 255) / 256)), dim3(256), 0, s, a.z0, T, a.ls0, a.lsn0);  // z0 | z1 are contiguous
     hipLaunchKernelGGL(assign_row_stats, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(assign_col_stats, dim3((a.N + 63) / 64, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(assign_col_stats, dim3((a.N + 63) / 64, a.B), dim3(64 * ACW), 0, s, a);
     const long long rows1 = (long long)a.B * (a.M + 1);
     hipLaunchKernelGGL(assign_rows, dim3((unsigned)((rows1 + 3) / 4)), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(assign_cols, dim3((a.N + 63) / 64, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(assign_cols, dim3((a.N + 63) / 64, a.B), dim3(64 * ACW), 0, s, a);
     const int L = a.M > a.N ? a.M : a.N;
     hipLaunchKernelGGL(assign_filter, dim3((L + 255) / 256, a.B), dim3(256), 0, s, a);
 }
