@@ -137,6 +137,7 @@ struct SampleArgs {
     const float* dense = nullptr;      // NHWC (B,hc,wc,256), normalised
     int B = 0, K = 0, hc = 0, wc = 0;
     int mode = 0;
+    int normalize_cells = 0;           // 1: `dense` is NOT normalised yet; L2-normalise the four sampled cells on the fly
     float* desc = nullptr;             // (B,K,256)
 };
 void launch_sample(const SampleArgs& a, hipStream_t s);

@@ -339,7 +339,13 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p, float d
     const float* dense = p.dense + (long long)b * p.hc * p.wc * 256;
     auto corner = [&](int yy, int xx) -> f32x4 {
         if (yy < 0 || yy >= p.hc || xx < 0 || xx >= p.wc) return f32x4{0.f, 0.f, 0.f, 0.f};
-        return *reinterpret_cast<const f32x4*>(dense + ((long long)yy * p.wc + xx) * 256 + lane * 4);
+        f32x4 v = *reinterpret_cast<const f32x4*>(dense + ((long long)yy * p.wc + xx) * 256 + lane * 4);
+        if (p.normalize_cells) {  // F.normalize of the cell, same arithmetic as l2norm_rows_kernel (the dense map is not needed)
+            const float cs = wave_sum(v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w);
+            const float cd = fmaxf(sqrtf(cs), 1e-12f);
+            v.x /= cd; v.y /= cd; v.z /= cd; v.w /= cd;
+        }
+        return v;
     };
     const f32x4 vnw = corner(y0, x0), vne = corner(y0, x0 + 1), vsw = corner(y0 + 1, x0), vse = corner(y0 + 1, x0 + 1);
     f32x4 o;
