@@ -23,23 +23,14 @@ namespace {
 constexpr int CT = 512;  // threads per workgroup of the 8-wave arrangements
 
 // Phase ablations used for the numbers in DESIGN.md: compile this file with -DCONV_ABL=<n> into a second library and
-// run bench.py with MG_LIB_PATH pointing at it (same box, same clocks).  7 = epilogue without its stores, 9 = conv1a
-// produced for the first chunk only, 10 = no weight re-staging, 11 = no MFMA phase.  Results are wrong by design.
+// run bench.py with MG_LIB_PATH pointing at it (same box, same clocks).  7 = epilogue without its stores (results are
+// wrong by design).  Earlier variants measured conv1ab's phases: conv1a for the first chunk only, no weight re-staging,
+// no MFMA phase.
 
-// Workgroups are dealt round-robin over the 8 XCDs, each with a private L2.  Re-number them so that one XCD works
-// through a CONTIGUOUS run of (image, tile, cout slice) items with the slice index fastest: the cout slices of a
+// Work-item order (item_of / tile_of in the kernels): workgroups are dealt round-robin over the 8 XCDs, each with a
+// private L2; ids are re-numbered so that one XCD works through a CONTIGUOUS run of (image, tile, cout slice) items with the slice index fastest: the cout slices of a
 // pixel tile (which read the same input tile) and spatially adjacent tiles (which share halo rows / columns) are
 // then in flight on the same L2 at the same time instead of being fetched from HBM once per XCD.
-__device__ __forceinline__ void xcd_item(int tiles, int nslices, int& tile, int& slice, int& b) {
-    const int total = gridDim.x, id = blockIdx.x;
-    int logical = id;
-    if ((total & 7) == 0) logical = (id & 7) * (total >> 3) + (id >> 3);
-    slice = logical % nslices;
-    const int r = logical / nslices;
-    tile = r % tiles;
-    b = r / tiles;
-}
-
 
 // One 16-channel chunk of a 3x3 convolution for a wave's 64 couts x 64 pixels: 9 taps x (8 fragment reads, 12
 // MFMAs).  Software-pipelined by hand: the 8 ds_read_b128 of tap k+1 are issued BEFORE the MFMAs of tap k (two
@@ -162,19 +153,6 @@ __device__ __forceinline__ void epilogue_sh8(f32x16 (&acc)[2][2], u32x4* __restr
     }
 }
 
-// accumulators start at the bias of their output channel (register r of a lane: channel cb + 8*(r>>2) + 4*h + (r&3))
-__device__ __forceinline__ void init_acc_bias(f32x16 (&acc)[2][2], const float* __restrict__ bias, int n0, int Cout, int h) {
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = n0 + mt * 32 + 8 * (r >> 2) + 4 * h + (r & 3);
-            const float bl = bias[min(ch, Cout - 1)];  // clamped load + select: no exec-mask branch per register
-            const float bv = ch < Cout ? bl : 0.f;
-            acc[mt][0][r] = bv;
-            acc[mt][1][r] = bv;
-        }
-}
 
 // Epilogue of one 64-cout x (4 x 16)-pixel wave tile.  `sb` = the 64 biases of this cout slice in LDS (nullptr when
 // the accumulators were initialised with the bias).  Hot path: ReLU + SH8 (+ pool); generic path below it.
@@ -434,6 +412,7 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
 // into the double-buffered conv1b input tile.  Waves 0-3 produce the next chunk and then multiply the
 // current one, waves 4-7 do it in the opposite order: SIMD partners (w, w+4) are always in opposite
 // phases, so the VALU work of one runs under the MFMAs of the other.
+template <bool GENERIC>
 __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args p, const Conv1aArgs c1) {
     constexpr int WY = 4, WX = 2;
     constexpr int TH = 4 * WY, TW = 16 * WX;
@@ -441,19 +420,58 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
     constexpr int NPIX = (TH + 2) * (TW + 2);
     constexpr int NWT = (9 * 64 * 4 + CT - 1) / CT;
     constexpr int GH = TH + 4, GW = TW + 4, GP = GW + 1;
+    constexpr int NG = (GH * GW + CT - 1) / CT;
     __shared__ u32x4 s_in[2][(TH + 2) * PW * 4];
     __shared__ u32x4 s_w[9 * 64 * 4];
     __shared__ float s_g[GH * GP];
     __shared__ __attribute__((aligned(16))) float s_c1[12 * 64];  // conv1a: [9 taps][64 ch] | bias | post_scale | post_shift
+    __shared__ __attribute__((aligned(16))) float s_bias[64];     // conv1b bias (Cout = 64: one cout slice)
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wu = __builtin_amdgcn_readfirstlane(wave);
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
-    int tile, slice, b;
-    xcd_item(tiles_x * tiles_y, (p.Cout + 63) / 64, tile, slice, b);
-    const int y0 = (tile / tiles_x) * TH, x0 = (tile % tiles_x) * TW;
-    const int n0 = slice * 64;
+    const int tiles = tiles_x * tiles_y, total = tiles * p.B;
     const u32x4* wt = reinterpret_cast<const u32x4*>(p.Wt);
+
+    // Persistent: the workgroup walks tiles in the XCD-contiguous order of xcd_item and treats their 16-channel chunks
+    // as one stream -- while the last chunk of a tile is multiplied, conv1a already produces the first chunk of the
+    // NEXT tile (its gray tile was fetched two chunks earlier), so only the epilogue separates two tiles' MFMA phases.
+    struct Tile { int b, y0, x0; };
+    auto tile_of = [&](int id) {
+        int logical = id;
+        if ((total & 7) == 0) logical = (id & 7) * (total >> 3) + (id >> 3);
+        const int tl = logical % tiles;
+        return Tile{logical / tiles, (tl / tiles_x) * TH, (tl % tiles_x) * TW};
+    };
+    // gray tile (RGB -> gray as superpoint.py:204-206), zero outside the image: global -> registers -> s_g
+    float rg[NG];
+    auto load_gray = [&](const Tile& tl) {
+        const long long HW = (long long)c1.H * c1.W;
+        const float* img = c1.image + (long long)tl.b * c1.C * HW;
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = t + CT * k;
+            const int gy = i / GW, gx = i - gy * GW;
+            const int yy = tl.y0 + gy - 2, xx = tl.x0 + gx - 2;
+            float v = 0.f;
+            if (i < GH * GW && yy >= 0 && yy < c1.H && xx >= 0 && xx < c1.W) {
+                const long long o = (long long)yy * c1.W + xx;
+                if (c1.C == 3)
+                    v = __fadd_rn(__fadd_rn(__fmul_rn(img[o], 0.299f), __fmul_rn(img[HW + o], 0.587f)), __fmul_rn(img[2 * HW + o], 0.114f));
+                else
+                    v = img[o];
+            }
+            rg[k] = v;
+        }
+    };
+    auto store_gray = [&]() {
+#pragma unroll
+        for (int k = 0; k < NG; ++k) {
+            const int i = t + CT * k;
+            const int gy = i / GW, gx = i - gy * GW;
+            if (i < GH * GW) s_g[gy * GP + gx] = rg[k];
+        }
+    };
 
     for (int i = t; i < 12 * 64; i += CT) {
         const int k = i >> 6, ch = i & 63;
@@ -464,31 +482,14 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
         else v = c1.post_shift ? c1.post_shift[ch] : 0.f;
         s_c1[i] = v;
     }
-    // gray tile (RGB -> gray as superpoint.py:204-206), zero outside the image
-    {
-        const long long HW = (long long)c1.H * c1.W;
-        const float* img = c1.image + (long long)b * c1.C * HW;
-        for (int i = t; i < GH * GW; i += CT) {
-            const int gy = i / GW, gx = i - gy * GW;
-            const int yy = y0 + gy - 2, xx = x0 + gx - 2;
-            float v = 0.f;
-            if (yy >= 0 && yy < c1.H && xx >= 0 && xx < c1.W) {
-                const long long o = (long long)yy * c1.W + xx;
-                if (c1.C == 3)
-                    v = __fadd_rn(__fadd_rn(__fmul_rn(img[o], 0.299f), __fmul_rn(img[HW + o], 0.587f)), __fmul_rn(img[2 * HW + o], 0.114f));
-                else
-                    v = img[o];
-            }
-            s_g[gy * GP + gx] = v;
-        }
-    }
+    if (t < 64) s_bias[t] = t < p.Cout ? p.bias[t] : 0.f;
 
     u32x4 rwt[NWT];
     auto load_w = [&](int c) {
 #pragma unroll
         for (int i = 0; i < NWT; ++i) {
             const int idx = t + CT * i, row = idx >> 2, q = idx & 3, tap = row >> 6, n = row & 63;
-            rwt[i] = (idx < 9 * 64 * 4) ? wt[((long long)(c * 9 + tap) * p.CoutPad + n0 + n) * 4 + q] : u32x4{0u, 0u, 0u, 0u};
+            rwt[i] = (idx < 9 * 64 * 4) ? wt[((long long)(c * 9 + tap) * p.CoutPad + n) * 4 + q] : u32x4{0u, 0u, 0u, 0u};
         }
     };
     auto store_w = [&]() {
@@ -502,7 +503,7 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
     // group (uniform) and three halo pixels per lane; the filter taps come from the LDS table s_c1 ([tap][channel],
     // every lane reads the same address = broadcast) -- as scalar loads they were ~50 dependent round trips per
     // chunk and made this phase 4x longer than the MFMA phase it is meant to hide under.
-    auto produce = [&](int c, int buf) {
+    auto produce = [&](int c, int buf, int y0, int x0) {
         const int gg = wu & 1;              // 8-channel group of this wave (uniform)
         const int ch0 = c * 16 + gg * 8;
         const int hp0 = (wu >> 1) * 64 + lane;
@@ -569,7 +570,6 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
     const int wy0 = (wave / WX) * 4, wx0 = (wave % WX) * 16;
     const int i32 = lane & 31, h = lane >> 5;
     f32x16 acc[2][2];
-    init_acc_bias(acc, p.bias, n0, p.Cout, h);
     const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
     const int wsw = (i32 >> 2) & 3;
     const int a_hi = i32 * 4 + ((2 * h) ^ wsw), a_lo = i32 * 4 + ((2 * h + 1) ^ wsw);
@@ -578,92 +578,44 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
         multiply_chunk_pipelined<PW>(reinterpret_cast<const f16x8*>(s_in[buf]), reinterpret_cast<const f16x8*>(s_w), P0, h, a_hi, a_lo, acc);
     };
 
-    const int nchunks = 4;  // conv1a has 64 output channels
+    int id = blockIdx.x;
+    if (id >= total) return;
+    Tile cur = tile_of(id);
+    load_gray(cur);
     load_w(0);
-    __syncthreads();          // gray tile ready
-    produce(0, 0);
+    store_gray();
+    __syncthreads();          // gray tile, tap table and bias table ready
+    produce(0, 0, cur.y0, cur.x0);
     store_w();
     __syncthreads();
-    for (int c = 0; c < nchunks; ++c) {
-        const int buf = c & 1;
-#if defined(CONV_ABL) && CONV_ABL == 9    // timing experiment 9: conv1a produced for the first chunk only
-        if (c + 1 < nchunks) load_w(c + 1);
-        multiply(0);
-#elif defined(CONV_ABL) && CONV_ABL == 10  // timing experiment 10: no weight re-staging
-        if (wu < 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
-        multiply(buf);
-        if (wu >= 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
-#elif defined(CONV_ABL) && CONV_ABL == 11  // timing experiment 11: no MFMA phase at all
-        if (c + 1 < nchunks) load_w(c + 1);
-        if (c + 1 < nchunks) produce(c + 1, buf ^ 1);
-#else
-        if (c + 1 < nchunks) load_w(c + 1);
-        if (wu < 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
-        multiply(buf);
-        if (wu >= 4 && c + 1 < nchunks) produce(c + 1, buf ^ 1);
-#endif
-        __syncthreads();      // everyone is done with s_w and s_in[buf]
-#if !(defined(CONV_ABL) && CONV_ABL == 10)
-        if (c + 1 < nchunks) {
-            store_w();
+    for (;;) {
+        const bool more = id + (int)gridDim.x < total;
+        const Tile nxt = tile_of(more ? id + (int)gridDim.x : id);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+#pragma unroll 1
+        for (int c = 0; c < 4; ++c) {  // conv1a has 64 output channels = 4 chunks; chunk parity == buffer
+            const int buf = c & 1;
+            const bool feed = c < 3 || more;  // the stage after this one exists
+            if (feed) load_w((c + 1) & 3);
+            if (c == 1 && more) load_gray(nxt);
+            const int py0 = c < 3 ? cur.y0 : nxt.y0, px0 = c < 3 ? cur.x0 : nxt.x0;
+            if (wu < 4 && feed) produce((c + 1) & 3, buf ^ 1, py0, px0);
+            multiply(buf);
+            if (wu >= 4 && feed) produce((c + 1) & 3, buf ^ 1, py0, px0);
+            __syncthreads();      // everyone is done with s_w, s_in[buf] and (after chunk 2's produce) s_g
+            if (feed) store_w();
+            if (c == 2 && more) store_gray();
             __syncthreads();
         }
-#endif
-    }
-
-    // ---- epilogue: identical to conv3x3_f16x3_kernel with pool = 1, SH8 output ----------------------
-    if (!p.post_scale) {
-        u32x4* oimg = reinterpret_cast<u32x4*>(p.out) + (long long)b * (p.H >> 1) * (p.W >> 1) * (p.Cout >> 2);
-        epilogue_sh8<true>(acc, oimg, p.H, p.W, p.Cout, y0 + wy0, x0 + wx0, n0, lane);
-        return;
-    }
-    const int Ho = p.H / 2, Wo = p.W / 2;
-    const int blk = i32 >> 2;
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-        const int cb = n0 + mt * 32;
-        float ps[16], pt[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int ch = cb + 8 * (r >> 2) + 4 * h + (r & 3);
-            const bool ok = ch < p.Cout;
-            ps[r] = (p.post_scale && ok) ? p.post_scale[ch] : 1.f;
-            pt[r] = (p.post_shift && ok) ? p.post_shift[ch] : 0.f;
-        }
-#pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            float v[16];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float x = acc[mt][nt][r];  // bias is already in the accumulator
-                x = fmaxf(x, 0.f);
-                if (p.post_scale) x = __fadd_rn(__fmul_rn(x, ps[r]), pt[r]);
-                x = fmaxf(x, dpp_quad_xor1(x));
-                x = fmaxf(x, dpp_quad_xor2(x));
-                v[r] = x;
-            }
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                half_swap(v[e], v[8 + e]);
-                half_swap(v[4 + e], v[12 + e]);
-            }
-            const f32x8 g0 = {v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]};
-            const f32x8 g1 = {v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]};
-            const int oy = (y0 + wy0 + 2 * nt) >> 1;
-            const int ox = ((x0 + wx0) >> 1) + blk;
-            const int ch0 = cb + 16 * h;
-            if (oy < Ho && ox < Wo && ch0 < p.Cout) {
-                // the four lanes of a quad hold the same pooled values: each writes one 16-byte piece
-                const long long pix = ((long long)b * Ho + oy) * Wo + ox;
-                f16x8 hi0, lo0, hi1, lo1;
-                split8(g0, hi0, lo0);
-                split8(g1, hi1, lo1);
-                const int ql = i32 & 3;
-                reinterpret_cast<u32x4*>(p.out)[(pix * p.Cout + ch0) / 4 + ql] =
-                    quad_pick(__builtin_bit_cast(u32x4, hi0), __builtin_bit_cast(u32x4, lo0), __builtin_bit_cast(u32x4, hi1),
-                              __builtin_bit_cast(u32x4, lo1), ql);
-            }
-        }
+        conv_epilogue<GENERIC>(p, acc, s_bias, cur.b, cur.y0 + wy0, cur.x0 + wx0, 0, lane);
+        if (!more) break;
+        cur = nxt;
+        id += gridDim.x;
     }
 }
 
@@ -763,8 +715,10 @@ void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
 }
 
 void launch_conv1ab_f16x3(const ConvF16Args& a, const Conv1aArgs& c1, hipStream_t s) {
-    dim3 grid(((a.H + 15) / 16) * ((a.W + 31) / 32) * ((a.Cout + 63) / 64) * a.B);
-    hipLaunchKernelGGL(conv1ab_f16x3_kernel, grid, dim3(CT), 0, s, a, c1);
+    const long long items = (long long)((a.H + 15) / 16) * ((a.W + 31) / 32) * a.B;  // Cout = 64: one cout slice
+    dim3 grid((unsigned)std::min<long long>(items, cu_count()));                     // persistent, one workgroup per CU (135 KB of LDS)
+    if (a.post_scale) hipLaunchKernelGGL(conv1ab_f16x3_kernel<true>, grid, dim3(CT), 0, s, a, c1);
+    else hipLaunchKernelGGL(conv1ab_f16x3_kernel<false>, grid, dim3(CT), 0, s, a, c1);
 }
 
 void launch_conv1a_sh8(const Conv1aArgs& a, hipStream_t s) {
