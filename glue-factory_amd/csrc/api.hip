@@ -1437,7 +1437,7 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
 int mg_nn_forward(mg_handle h, const mg_nn_conf* conf, const float* desc0, const float* desc1, int B, int M, int N, int D, int64_t* matches0,
                   int64_t* matches1, float* mscores0, float* mscores1, float* similarity, float* log_assignment, void* stream) {
     if (!h || !conf || !desc0 || !desc1 || !matches0 || !matches1 || !mscores0 || !mscores1) return fail(MG_ERR_ARG, "NULL argument");
-    if (B < 1 || M < 1 || N < 1 || D < 16 || (D & 15)) return fail(MG_ERR_ARG, "bad shape (descriptor dim must be a multiple of 16)");
+    if (B < 1 || M < 1 || N < 1 || D < 1) return fail(MG_ERR_ARG, "bad shape");
     if (conf->ratio_thresh > 0.f && (M < 2 || N < 2))
         return fail(MG_ERR_ARG, "ratio test needs two candidates per side (the reference's topk(2) raises as well)");
     HIPCHK(hipSetDevice(h->device));
@@ -1447,6 +1447,17 @@ int mg_nn_forward(mg_handle h, const mg_nn_conf* conf, const float* desc0, const
     float* SIM = similarity ? similarity : h->buf("lg.sim", (size_t)B * M * N);
     float* ST = h->buf("lg.stats", 6 * (T0 + T1) + 16);
     if (!SIM || !ST) return fail(MG_ERR_HIP, "workspace allocation failed");
+    if (D & 15) {  // the GEMMs contract in steps of 16: zero-pad the descriptor rows (zeros add nothing to a dot product)
+        const int Dp = (D + 15) & ~15;
+        float* PD = h->buf("nn.pad", (T0 + T1) * Dp);
+        if (!PD) return fail(MG_ERR_HIP, "workspace allocation failed");
+        HIPCHK(hipMemsetAsync(PD, 0, (T0 + T1) * Dp * sizeof(float), s));
+        HIPCHK(hipMemcpy2DAsync(PD, Dp * sizeof(float), desc0, D * sizeof(float), D * sizeof(float), T0, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpy2DAsync(PD + T0 * Dp, Dp * sizeof(float), desc1, D * sizeof(float), D * sizeof(float), T1, hipMemcpyDeviceToDevice, s));
+        desc0 = PD;
+        desc1 = PD + T0 * Dp;
+        D = Dp;
+    }
     {
         ProfScope ps(h, s, "nn.gemm.sim");
         if (f16) {

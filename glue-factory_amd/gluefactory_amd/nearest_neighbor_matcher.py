@@ -6,7 +6,8 @@ Drop-in for `gluefactory.models.matchers.nearest_neighbor_matcher`
 (`matches0/1` int64 with -1 = unmatched, `matching_scores0/1` in {0,1}, `similarity` (B,M,N), `log_assignment`
 (B,M+1,N+1)).  No weights; the forward is one call into libmatchglue (`mg_nn_forward`).
 
-Among exactly equal similarities the lowest index wins (torch.topk leaves that order unspecified).
+Among exactly equal similarities the lowest index wins (torch.topk leaves that order unspecified); descriptors of any
+width are accepted (rows are zero-padded to the GEMM step inside the library).
 """
 import torch
 

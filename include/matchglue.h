@@ -163,7 +163,8 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
 /* -- nearest-neighbour matcher ------------------------------------------------
  * gluefactory/models/matchers/nearest_neighbor_matcher.py:51-72: sim = desc0 . desc1^T, best (and second best for
  * the ratio test) per row and per column, thresholds on d = 2(1 - sim), optional mutual check. No weights.
- * desc0 (B,M,D), desc1 (B,N,D), D a multiple of 16. A threshold <= 0 is "off" (the reference's None).
+ * desc0 (B,M,D), desc1 (B,N,D), any D (rows are zero-padded to a multiple of 16 internally). A threshold <= 0 is "off"
+ * (the reference's None).
  * similarity optional (B,M,N); log_assignment optional (B,M+1,N+1) (double log-softmax, zero last row/column). */
 typedef struct mg_nn_conf {
     float ratio_thresh;

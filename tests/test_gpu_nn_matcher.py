@@ -99,7 +99,11 @@ def test_nn_matcher_contract(dev):
         m({"descriptors0": d})
     with pytest.raises(RuntimeError):
         m({"descriptors0": d[:, :1], "descriptors1": d})  # ratio test with a single candidate: the reference's topk(2) raises too
-    with pytest.raises(RuntimeError):
-        m({"descriptors0": d[..., :20].contiguous(), "descriptors1": d[..., :20].contiguous()})  # D % 16 != 0
+    # any descriptor width: rows are zero-padded to the GEMM's 16-step internally
+    d20 = torch.nn.functional.normalize(d[..., :20], dim=-1).contiguous()
+    ref = O.nn_forward({"descriptors0": d20.cpu(), "descriptors1": d20.cpu().flip(1)})
+    got = _module({}, "f16x3")({"descriptors0": d20, "descriptors1": d20.flip(1).contiguous()})
+    assert torch.equal(got["matches0"].cpu(), ref["matches0"])
+    torch.testing.assert_close(got["similarity"].cpu(), ref["similarity"], rtol=0, atol=2e-6)
     p = _module({}, "f16x3")({"descriptors0": d, "descriptors1": d})  # identical sets: identity matching
     assert torch.equal(p["matches0"].cpu(), torch.arange(8)[None])
