@@ -38,12 +38,13 @@ def shard_batch(data, rank, world_size):
     return cut(data)
 
 
-def all_gather_matches(pred, group=None, with_keypoints=False):
+def all_gather_matches(pred, group=None, with_keypoints=False, force=False):
     """All-gather the match outputs of every rank (equal shard sizes) -> full-batch tensors on all ranks.
 
-    One packed buffer per rank -> a single all_gather_into_tensor call.
+    One packed buffer per rank -> a single all_gather_into_tensor call.  `force` runs the collective even in a
+    one-rank group (used by the single-GPU test of the RCCL path).
     """
-    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
         return {k: pred[k] for k in GATHER_KEYS + (OPTIONAL_KEYS if with_keypoints else ()) if k in pred}
     world = dist.get_world_size(group)
     keys = [k for k in GATHER_KEYS + (OPTIONAL_KEYS if with_keypoints else ()) if k in pred]

@@ -395,3 +395,28 @@ def test_fused_views_equal_separate_calls(dev):
         outs.append(pipe({"view0": {"image": im[:2]}, "view1": {"image": im[2:]}}))
     for k in outs[0]:
         assert torch.equal(outs[0][k], outs[1][k]), k
+
+
+def test_all_gather_matches_rccl_single_rank(dev):
+    """The RCCL leg of the multi-GPU path on the one GPU a test box has: a one-rank "nccl" group must return the packed
+    int32 / fp32 buffer unchanged (indices widened back to int64)."""
+    import torch.distributed as dist
+
+    from gluefactory_amd.parallel import all_gather_matches
+
+    if dist.is_initialized():
+        pytest.skip("a process group already exists in this process")
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
+    try:
+        g = torch.Generator().manual_seed(3)
+        pred = {"matches0": torch.randint(-1, 100, (4, 128), generator=g).to(dev), "matches1": torch.randint(-1, 128, (4, 100), generator=g).to(dev),
+                "matching_scores0": torch.rand(4, 128, generator=g).to(dev), "matching_scores1": torch.rand(4, 100, generator=g).to(dev),
+                "keypoints0": torch.rand(4, 128, 2, generator=g).to(dev)}
+        out = all_gather_matches(pred, force=True)
+        assert sorted(out) == ["matches0", "matches1", "matching_scores0", "matching_scores1"]
+        for k, v in out.items():
+            assert v.dtype == pred[k].dtype and torch.equal(v, pred[k]), k
+        out = all_gather_matches(pred, with_keypoints=True, force=True)
+        assert torch.equal(out["keypoints0"], pred["keypoints0"])
+    finally:
+        dist.destroy_process_group()
