@@ -156,9 +156,15 @@ struct SinkFusedArgs {
 // relative on every term that is not already negligible (x > -30)
 __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x * 1.4426950408889634f); }
 
+// Exponentials are spent ONCE per coupling: the row half-step leaves e_ij = exp(z_ij + v_j - m_i) in the registers
+// that held z_ij; with a_i = exp(u_i + m_i) (one value per row) the column sums are
+//   sum_i exp(z_ij + u_i) = exp(-v_j) * sum_i e_ij * a_i,
+// i.e. plain FMAs.  e and a are <= 1, so nothing overflows; a column whose total falls below 1e-20 (its potential
+// moved by more than ~46 in one iteration: possible in the first iterations on extreme costs) is recomputed exactly,
+// in the log domain, by sinkhorn_combine_kernel.
 __global__ __launch_bounds__(64 * FW, 2) void sinkhorn_fused_kernel(const SinkFusedArgs q) {
     const SinkArgs& p = q.a;
-    __shared__ float s_m[FW][2052], s_l[FW][2052];
+    __shared__ float s_l[FW][2052];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
     const int b = blockIdx.y, blk = blockIdx.x;
     const int nq = p.N >> 2;
@@ -168,12 +174,9 @@ __global__ __launch_bounds__(64 * FW, 2) void sinkhorn_fused_kernel(const SinkFu
     const float vbin = v[p.N];
 
     f32x4 z[4][8];
-    float ui[4];
-    bool live[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
         const int i = blk * FR + w + FW * k;
-        live[k] = i <= p.M;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
             const int qd = lane + 64 * g;
@@ -181,128 +184,99 @@ __global__ __launch_bounds__(64 * FW, 2) void sinkhorn_fused_kernel(const SinkFu
             if (i < p.M && qd < nq) z[k][g] = *reinterpret_cast<const f32x4*>(c + (long long)i * p.N + 4 * qd);
         }
     }
-    // row half-step
-    {
-        f32x4 vv[8];
+    f32x4 vv[8];
 #pragma unroll
-        for (int g = 0; g < 8; ++g) {
-            const int qd = lane + 64 * g;
-            vv[g] = qd < nq ? *reinterpret_cast<const f32x4*>(v + 4 * qd) : f32x4{0.f, 0.f, 0.f, 0.f};
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            float m = (lane == 0) ? p.alpha + vbin : -__builtin_inff();
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-                if (lane + 64 * g < nq) {
-                    const f32x4 x = z[k][g] + vv[g];
-                    m = fmaxf(m, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
-                }
-            m = wave_max(m);
-            float s = (lane == 0) ? fexp(p.alpha + vbin - m) : 0.f;
-#pragma unroll
-            for (int g = 0; g < 8; ++g)
-                if (lane + 64 * g < nq) {
-                    const f32x4 x = z[k][g] + vv[g];
-                    s += (fexp(x[0] - m) + fexp(x[1] - m)) + (fexp(x[2] - m) + fexp(x[3] - m));
-                }
-            s = wave_sum(s);
-            const int i = blk * FR + w + FW * k;
-            ui[k] = (i < p.M ? p.norm : p.log_mu_bin) - (logf(s) + m);
-            if (lane == 0 && live[k]) u[i] = ui[k];
-        }
+    for (int g = 0; g < 8; ++g) {
+        const int qd = lane + 64 * g;
+        vv[g] = qd < nq ? *reinterpret_cast<const f32x4*>(v + 4 * qd) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    // column half-step over this wave's rows
-    const float NEG = -__builtin_inff();
+    float ebin[4], ai[4];  // dustbin-column exponential and a_i of this wave's rows
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = blk * FR + w + FW * k;
+        const bool live = i <= p.M;
+        // row half-step: z <- z + v, row max, z <- exp(z - m), row sum
+        float m = p.alpha + vbin;
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (lane + 64 * g < nq) {
+                z[k][g] += vv[g];
+                m = fmaxf(m, fmaxf(fmaxf(z[k][g][0], z[k][g][1]), fmaxf(z[k][g][2], z[k][g][3])));
+            }
+        m = wave_max(m);
+        ebin[k] = fexp(p.alpha + vbin - m);
+        float sum = (lane == 0) ? ebin[k] : 0.f;
+#pragma unroll
+        for (int g = 0; g < 8; ++g)
+            if (lane + 64 * g < nq) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) z[k][g][e] = fexp(z[k][g][e] - m);
+                sum += (z[k][g][0] + z[k][g][1]) + (z[k][g][2] + z[k][g][3]);
+            }
+        sum = wave_sum(sum);
+        const float ui = (i < p.M ? p.norm : p.log_mu_bin) - (logf(sum) + m);
+        if (lane == 0 && live) u[i] = ui;
+        ai[k] = live ? fexp(ui + m) : 0.f;  // = mu_i / sum <= 1; 0 switches a row past the end off
+    }
+    // column half-step: S_j = sum over this wave's rows of e_ij * a_i
 #pragma unroll
     for (int g = 0; g < 8; ++g) {
         const int qd = lane + 64 * g;
         if (qd >= nq) continue;
-        f32x4 cm = {NEG, NEG, NEG, NEG};
+        f32x4 cl = z[0][g] * ai[0];
 #pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (live[k])
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cm[e] = fmaxf(cm[e], z[k][g][e] + ui[k]);
-        f32x4 cl = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (live[k])
-#pragma unroll
-                for (int e = 0; e < 4; ++e) cl[e] += fexp(z[k][g][e] + ui[k] - cm[e]);
-        *reinterpret_cast<f32x4*>(&s_m[w][4 * qd]) = cm;
+        for (int k = 1; k < 4; ++k) cl += z[k][g] * ai[k];
         *reinterpret_cast<f32x4*>(&s_l[w][4 * qd]) = cl;
     }
-    if (lane == 0) {  // dustbin column: alpha in every row
-        float cm = NEG, cl = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (live[k]) cm = fmaxf(cm, p.alpha + ui[k]);
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (live[k]) cl += fexp(p.alpha + ui[k] - cm);
-        s_m[w][p.N] = cm;
-        s_l[w][p.N] = cl;
-    }
+    if (lane == 0) s_l[w][p.N] = (ebin[0] * ai[0] + ebin[1] * ai[1]) + (ebin[2] * ai[2] + ebin[3] * ai[3]);
     __syncthreads();
-    float* pm = q.pm + ((long long)b * q.nblk + blk) * p.vstride;
     float* pl = q.pl + ((long long)b * q.nblk + blk) * p.vstride;
     for (int j = t; j <= p.N; j += 64 * FW) {
-        float mm = s_m[0][j];
+        float ll = s_l[0][j];
 #pragma unroll
-        for (int k = 1; k < FW; ++k) mm = fmaxf(mm, s_m[k][j]);
-        float ll = 0.f;
-#pragma unroll
-        for (int k = 0; k < FW; ++k)
-            if (s_l[k][j] > 0.f) ll += s_l[k][j] * fexp(s_m[k][j] - mm);
-        pm[j] = mm;
+        for (int k = 1; k < FW; ++k) ll += s_l[k][j];
         pl[j] = ll;
     }
 }
 
-// v_j = log_nu_j - logsumexp over the row-block partials of column j.  64 columns per workgroup, 4 waves take
-// interleaved blocks in batches of 8 independent loads.
+// v_j = log_nu_j - log(sum_i exp(z_ij + u_i)) with sum_i exp(z_ij + u_i) = exp(-v_j) * (sum of the row-block partials).
+// 64 columns per workgroup, 4 waves take interleaved blocks in batches of 8 independent loads.  A column whose total
+// underflowed is recomputed exactly from the couplings (log-sum-exp over its M+1 rows with the fresh u).
 __global__ __launch_bounds__(256) void sinkhorn_combine_kernel(const SinkFusedArgs q) {
     const SinkArgs& p = q.a;
-    __shared__ float s_m[4][64], s_l[4][64];
+    __shared__ float s_l[4][64];
     const int b = blockIdx.y, cl = threadIdx.x & 63, j = blockIdx.x * 64 + cl, g = threadIdx.x >> 6;
-    float m = -__builtin_inff(), l = 0.f;
+    float l = 0.f;
     if (j <= p.N) {
-        const float* pm = q.pm + (long long)b * q.nblk * p.vstride + j;
         const float* pl = q.pl + (long long)b * q.nblk * p.vstride + j;
         for (int k0 = g; k0 < q.nblk; k0 += 32) {
-            float xm[8], xl[8];
+            float x[8];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const int k = k0 + 4 * e;
-                xm[e] = -__builtin_inff();
-                xl[e] = 0.f;
-                if (k < q.nblk) {
-                    xm[e] = pm[(long long)k * p.vstride];
-                    xl[e] = pl[(long long)k * p.vstride];
-                }
+                x[e] = k < q.nblk ? pl[(long long)k * p.vstride] : 0.f;
             }
-            float nm = m;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) nm = fmaxf(nm, xm[e]);
-            float acc = l > 0.f ? l * fexp(m - nm) : 0.f;
-#pragma unroll
-            for (int e = 0; e < 8; ++e)
-                if (xl[e] > 0.f) acc += xl[e] * fexp(xm[e] - nm);
-            l = acc;
-            m = nm;
+            l += ((x[0] + x[1]) + (x[2] + x[3])) + ((x[4] + x[5]) + (x[6] + x[7]));
         }
     }
-    s_m[g][cl] = m;
     s_l[g][cl] = l;
     __syncthreads();
     if (g == 0 && j <= p.N) {
-        const float mm = fmaxf(fmaxf(s_m[0][cl], s_m[1][cl]), fmaxf(s_m[2][cl], s_m[3][cl]));
-        float ll = 0.f;
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-            if (s_l[k][cl] > 0.f) ll += s_l[k][cl] * fexp(s_m[k][cl] - mm);
-        p.v[(long long)b * p.vstride + j] = (j < p.N ? p.norm : p.log_nu_bin) - (logf(ll) + mm);
+        const float ll = (s_l[0][cl] + s_l[1][cl]) + (s_l[2][cl] + s_l[3][cl]);
+        float* vj = p.v + (long long)b * p.vstride + j;
+        const float log_nu = j < p.N ? p.norm : p.log_nu_bin;
+        if (ll > 1e-20f) {
+            *vj = log_nu - (logf(ll) - *vj);
+        } else {  // rare: exact log-domain column (the other lanes of the wave idle meanwhile)
+            const float* u = p.u + (long long)b * (p.M + 1);
+            const float* c = p.cost + (long long)b * p.M * p.N;
+            float m = -__builtin_inff(), acc = 0.f;
+            for (int i = 0; i <= p.M; ++i) {
+                const float x = ((i < p.M && j < p.N) ? c[(long long)i * p.N + j] : p.alpha) + u[i];
+                if (x > m) { acc = acc * expf(m - x) + 1.f; m = x; } else acc += expf(x - m);
+            }
+            *vj = log_nu - (logf(acc) + m);
+        }
     }
 }
 

@@ -10,10 +10,15 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/prof_$tag" -o "$tag" -- \
     python3 "$root/bench.py" --no-cpu-baseline "$@" > "$root/gpurun_out/${tag}_prof.log" 2>&1
 f=$(find "$root/gpurun_out/prof_$tag" -name "*kernel_stats.csv" | head -1)
-cut -c1-240 "$f" > "$root/gpurun_out/${tag}_kernel_stats.csv"
-python3 - "$root/gpurun_out/${tag}_kernel_stats.csv" <<'PY'
+python3 - "$f" "$root/gpurun_out/${tag}_kernel_stats.csv" <<'PY'
 import csv, sys
 rows = list(csv.DictReader(open(sys.argv[1])))
+with open(sys.argv[2], "w", newline="") as fh:  # same columns, kernel names cut to 160 characters (template arguments run long)
+    w = csv.DictWriter(fh, fieldnames=list(rows[0].keys()))
+    w.writeheader()
+    for r in rows:
+        r["Name"] = r["Name"][:160]
+        w.writerow(r)
 for r in rows[:16]:
     print(f'{r["Name"][:64]:64s} {r["Calls"]:>6s} {float(r["AverageNs"]) / 1e3:9.1f} us {r["Percentage"]:>6s}%')
 PY
