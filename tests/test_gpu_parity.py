@@ -406,7 +406,12 @@ def test_all_gather_matches_rccl_single_rank(dev):
 
     if dist.is_initialized():
         pytest.skip("a process group already exists in this process")
-    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29533", rank=0, world_size=1, device_id=dev)
+    import socket
+
+    with socket.socket() as sk:  # any free port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1, device_id=dev)
     try:
         g = torch.Generator().manual_seed(3)
         pred = {"matches0": torch.randint(-1, 100, (4, 128), generator=g).to(dev), "matches1": torch.randint(-1, 128, (4, 100), generator=g).to(dev),
