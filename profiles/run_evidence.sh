@@ -3,6 +3,7 @@
 #   1. bench.py default (f16x3, with the CPU baseline) and --precision f32        -> gpurun_out/<tag>_*_bench.json
 #   2. rocprofv3 --kernel-trace --stats of the same command                        -> gpurun_out/<tag>_f16x3_kernel_stats.csv
 #   3. rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, kernel-trace only) -> gpurun_out/<tag>_f16x3_hbm_traffic.json
+#   4. rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE (profiles/run_mfma_pmc.sh)     -> gpurun_out/<tag>_f16x3_mfma_util.json
 # Copy what should be judged into profiles/.
 set -e
 tag=$1
@@ -23,6 +24,7 @@ f=$(find "$out/pmc_${tag}_FETCH_SIZE" -name "*counter_collection.csv" | head -1)
 w=$(find "$out/pmc_${tag}_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
 python3 profiles/summarize_pmc.py "$f" "$w" "$out/${tag}_f16x3_hbm_traffic.json" > /dev/null
 rm -rf "$out"/pmc_${tag}_* "$out"/prof_${tag}_*
+profiles/run_mfma_pmc.sh "$tag" > "$out/${tag}_mfma_summary.txt" 2>&1 || true
 (tests/micro/mfma_peak; tests/micro/bw_pattern) > "$out/${tag}_micro.txt" 2>&1 || true
 cat "$out/${tag}_micro.txt"
 cat "$out/${tag}_trace_summary.txt"
