@@ -20,7 +20,11 @@
 namespace {
 
 constexpr int TN = 256, TM = 256, BK = 16, GT = 512;  // 8 waves: 2 (features) x 4 (tokens), each 128 x 64
-constexpr int TSLOTS = 6, WSLOTS = 3;  // LDS rings: token stages (HBM) run 5 ahead, weight stages (L2) 2 ahead
+#ifndef MG_TSLOTS  // ring depths are compile-time knobs: (7,2) / (6,3) / (5,4) / (4,3) measured within 2 % of each other
+#define MG_TSLOTS 5
+#define MG_WSLOTS 4
+#endif
+constexpr int TSLOTS = MG_TSLOTS, WSLOTS = MG_WSLOTS;  // LDS rings: token stages (HBM) run TSLOTS-1 ahead, weight stages (L2) WSLOTS-1 ahead
 
 __device__ __forceinline__ int swz(int row, int q) { return row * 4 + (q ^ ((row >> 2) & 3)); }  // 64-byte rows
 
@@ -44,7 +48,7 @@ __device__ __attribute__((noinline)) void epilogue_ragged(const GemmF16Args& p, 
 template <bool W_ROWMAJOR, bool RAGGED>
 __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
     // ONE LDS array (a second __shared__ object next to LDS-DMA staging makes hipcc drain vmcnt before
-    // every fragment read): [token ring: 6 x 256 rows x 64 B][weight ring: 3 x 256 rows x 64 B] = 144 KB
+    // every fragment read): [token ring: TSLOTS x 256 rows x 64 B][weight ring: WSLOTS x 256 rows x 64 B] = 144 KB
     __shared__ u32x4 s_ring[(TSLOTS * TM + WSLOTS * TN) * 4 + 3 * TN / 4];  // + bias | post_scale | post_shift of this feature tile
     u32x4* const s_tokr = s_ring;
     u32x4* const s_wr = s_ring + TSLOTS * TM * 4;
@@ -82,8 +86,8 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
     // the DMA writes LDS linearly, so the XOR swizzle is applied to the per-lane SOURCE piece; rows
     // past the edge are clamped, their outputs are never stored).
     // These GEMMs are HBM-bound (K = 256..512) and vmcnt retires in issue order, so the two operand
-    // streams are issued by DIFFERENT waves with their own ring depth: the token waves keep five stages
-    // (80 KB per CU, 20 MB chip-wide) in flight behind counted vmcnt waits, the weight waves two.
+    // streams are issued by DIFFERENT waves with their own ring depth: the token waves keep TSLOTS-1 stages
+    // (64 KB per CU, 16 MB chip-wide) in flight behind counted vmcnt waits, the weight waves WSLOTS-1.
     auto issue_tok = [&](int kt) {
         const int k0 = kt * BK;
         u32x4* ring = s_tokr + (kt % TSLOTS) * TM * 4;
@@ -136,14 +140,17 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
         // each wave waits for ITS loads of stage kt: all but the younger stages of its own stream
         if (tok_wave) {
             const int ahead = min(TSLOTS - 2, nk - 1 - kt);
-            if (ahead == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            if (ahead == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
+            else if (ahead == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+            else if (ahead == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
             else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         } else {
             const int ahead = min(WSLOTS - 2, nk - 1 - kt);
-            if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __builtin_amdgcn_s_barrier();  // stage kt is complete in LDS; everyone is done with stage kt-1
