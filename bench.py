@@ -107,11 +107,11 @@ def cpu_baseline(pairs=4, matcher="lightglue"):
     dt = time.perf_counter() - t0
     pairs = n
     return {"value": round(pairs / dt, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{pairs} pairs of the same workload (640x480, {K} kpts), batch 1, {dt:.1f} s of CPU time"}
+            "sample": f"{pairs} pairs of the same workload ({W}x{H}, {K} kpts), batch 1, {dt:.1f} s of CPU time"}
 
 
 def main():
-    global K
+    global K, H, W
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
@@ -125,8 +125,10 @@ def main():
                          "gluestick: configs[4] with synthetic line segments between detected keypoints (LSD is a CPU dependency)")
     ap.add_argument("--lines", type=int, default=250, help="line segments per image (gluestick)")
     ap.add_argument("--kpts", type=int, default=K, help="keypoints per image")
+    ap.add_argument("--size", default=f"{W}x{H}", help="image WxH (default 640x480 = configs[1]; 1024x1024 with --kpts 2048 = the per-GPU share of configs[2])")
     args = ap.parse_args()
     K = args.kpts
+    W, H = (int(v) for v in args.size.lower().split("x"))
 
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -236,12 +238,12 @@ def main():
         import glob
         cands = sorted(glob.glob(os.path.join(ROOT, "profiles", f"r*_{args.precision}_hbm_traffic.json")))
         tpath = cands[-1] if cands else ""  # the newest committed PMC summary for this arithmetic mode
-        if tpath and B == PAIRS and args.matcher == "lightglue" and K == 1024:
+        if tpath and B == PAIRS and args.matcher == "lightglue" and K == 1024 and (W, H) == (640, 480):
             tj = json.load(open(tpath))
             if dom in tj:
                 traffic, traffic_src = tj[dom]["hbm_bytes_per_launch"], os.path.relpath(tpath, ROOT)
         res = {
-            "metric": ("image-pairs/sec SP+LightGlue (VGA, 1024 kpts) at 1/2/4/8 MI355X" if args.matcher == "lightglue" and K == 1024
+            "metric": ("image-pairs/sec SP+LightGlue (VGA, 1024 kpts) at 1/2/4/8 MI355X" if args.matcher == "lightglue" and K == 1024 and (W, H) == (640, 480)
                        else f"image-pairs/sec SP+{args.matcher} (VGA, {K} kpts)"),
             "value": round(world * B * args.steps / dt, 3),
             "unit": "pairs/s",
@@ -254,7 +256,7 @@ def main():
             "vs_baseline": None,
             "dtype": args.precision,
             "data": "synthetic",
-            "config": {"workload": (f"SuperPoint + LightGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[1])"
+            "config": {"workload": (f"SuperPoint + LightGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[{1 if (W, H, K) == (640, 480, 1024) else 2}])"
                                     if args.matcher == "lightglue" else
                                     f"SuperPoint + SuperGlue, {W}x{H}, {K} kpts, batch={B} pairs per GPU (BASELINE.json configs[3])"
                                     if args.matcher == "superglue" else
