@@ -11,6 +11,9 @@ imports) of the reference's hot path:
   * SuperPoint-open                /root/reference/gluefactory/models/extractors/superpoint_open.py:123-217
   * LightGlue (in-tree)            /root/reference/gluefactory/models/matchers/lightglue.py:399-525
   * TwoViewPipeline key plumbing   /root/reference/gluefactory/models/two_view_pipeline.py:62-90
+  * SuperGlue                      /root/reference/gluefactory_nonfree/superglue.py:253-307
+  * GlueStick                      /root/reference/gluefactory/models/matchers/gluestick.py:136-312
+  * nearest-neighbour matcher      /root/reference/gluefactory/models/matchers/nearest_neighbor_matcher.py:15-72
 
 Parity pin: `tests/golden/*.npz` were produced by importing the reference
 itself in the build container (`oracle/tools/make_goldens.py`); the oracle is
