@@ -72,7 +72,7 @@ def algorithmic_flops(B):
         "sg.gemm.qkv": lin(256, 768), "sg.gemm.mlp0": lin(512, 512), "sg.gemm.mlp3": lin(512, 256),
         "sg.gemm.final_proj": lin(256, 256), "sg.gemm.cost": 2.0 * B * K * K * 256,
         "sg.attn.self": 2 * (2.0 * 4 * K * K * 64) * 2 * B, "sg.attn.cross": 2 * (2.0 * 4 * K * K * 64) * 2 * B,
-        "gs.gemm.qkv": lin(256, 768), "gs.gemm.mlp": lin(512, 512) + lin(512, 256),
+        "gs.gemm.qkv": lin(256, 768), "gs.gemm.mlp0": lin(512, 512), "gs.gemm.mlp3": lin(512, 256),
         "gs.attn.self": 2 * (2.0 * 4 * K * K * 64) * 2 * B, "gs.attn.cross": 2 * (2.0 * 4 * K * K * 64) * 2 * B,
     }
     return f

@@ -169,6 +169,7 @@ struct ProfScope {
     ~ProfScope() {
         if (on) (void)hipEventRecord(h->prof[idx].b, s);
     }
+    ProfScope(mg_context* h_, hipStream_t s_, const std::string& name) : ProfScope(h_, s_, name.c_str()) {}
 };
 
 int upload(mg_context* h, const std::vector<float>& v, float** out) {
@@ -1087,6 +1088,111 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
 }
 
 // ------------------------------------------------------------------------------------------------
+// Shared by SuperGlue and GlueStick: one dispatcher for both arithmetic modes over the (T, .) token matrix.
+// "act" buffers hold SH8 rows in f16x3 mode and fp32 rows otherwise; X is the fp32 residual stream, XS its SH8 copy.
+struct GnnRun {
+    mg_context* h;
+    hipStream_t s;
+    bool f16;
+    int B, M, N;
+    size_t T0, T;
+    float *X, *XS, *QKV, *CTX, *HID, *P0;
+    struct Opt { int relu = 0; float scale = 1.f; int scale_cols = 0; const float* residual = nullptr; float* c32 = nullptr; int ldc32 = 0; };
+
+    float* xa() const { return f16 ? XS : X; }  // the GEMM-input view of the descriptor stream
+
+    void linear(const LinLayer& L, size_t rows, const float* A, int lda, const float* A1, int lda1, float* act_out, int ld_out, const Opt& o) const {
+        if (f16) {
+            GemmF16Args g = lin_args_f16(L, A, lda, (int)rows);
+            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
+            g.Cs = act_out; g.ldcs = ld_out; g.C = o.c32; g.ldc = o.ldc32;
+            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
+            launch_gemm_f16x3(g, s);
+        } else {
+            float* out = o.c32 ? o.c32 : act_out;
+            GemmArgs g = lin_args(L, A, lda, (int)rows, out, o.c32 ? o.ldc32 : ld_out);
+            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
+            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
+            launch_gemm(g, s);
+        }
+    }
+    // MLP([32 (padded input) -> 32, 64, 128, 256, 256]) on `rows` rows; in32 = fp32 input rows, in_sh8 = room for their SH8
+    // copy, t0 / t1 = ping-pong activations (>= rows x 256), the last layer goes where `last` / last_act say
+    void encoder(const LinLayer* enc, size_t rows, float* in32, float* in_sh8, float* t0, float* t1, float* last_act, const Opt& last) const {
+        const float* a = in32;
+        if (f16) { launch_to_sh8(in32, in_sh8, (long long)rows * 32, s); a = in_sh8; }
+        Opt relu; relu.relu = 1;
+        linear(enc[0], rows, a, 32, nullptr, 0, t0, 32, relu);
+        linear(enc[1], rows, t0, 32, nullptr, 0, t1, 64, relu);
+        linear(enc[2], rows, t1, 64, nullptr, 0, t0, 128, relu);
+        linear(enc[3], rows, t0, 128, nullptr, 0, t1, 256, relu);
+        linear(enc[4], rows, t1, 256, nullptr, 0, last_act, 256, last);
+    }
+    // desc += MLP([x, y, score]) for every keypoint (superglue.py:89-103, :275-276; gluestick.py:199-200)
+    void keypoint_encoder(const LinLayer* enc, const float* kpts0, const float* kpts1, const float* scores0, const float* scores1,
+                          const float* size0, const float* size1) const {
+        float* KIN = HID;  // (T,32) fp32 followed by its SH8 copy
+        launch_sg_kenc_input(kpts0, kpts1, scores0, scores1, size0, size1, B, M, N, KIN, s);
+        Opt last; last.residual = X; last.c32 = X; last.ldc32 = 256;
+        encoder(enc, T, KIN, HID + T * 32, P0, CTX, XS, last);
+    }
+    // one AttentionalPropagation block (superglue.py:118-141): x += MLP([x, merge(attention(x, source))]) with the merge
+    // projection folded into mlp.0 at upload; cross = attend to the other image of the pair
+    void layer(const mg_context::SgLayer& Lr, int cross, const char* tag) const {
+        const std::string t(tag);
+        {
+            ProfScope ps(h, s, t + ".gemm.qkv");
+            Opt o; o.scale = f16 ? 0.125f * 1.4426950408889634f : 0.125f; o.scale_cols = 256;  // / sqrt(64) (x log2 e in f16x3 mode)
+            linear(Lr.proj, T, xa(), 256, nullptr, 0, QKV, 768, o);
+        }
+        {
+            ProfScope ps(h, s, t + (cross ? ".attn.cross" : ".attn.self"));
+            if (f16) {
+                AttnF16Args a;
+                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
+                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+                launch_attention_f16x3(a, s);
+            } else {
+                AttnArgs a;
+                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
+                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+                launch_attention(a, s);
+            }
+        }
+        {
+            ProfScope ps(h, s, t + ".gemm.mlp0");
+            Opt o; o.relu = 1;
+            linear(Lr.mlp0f, T, xa(), 256, CTX, 256, HID, 512, o);
+        }
+        {
+            ProfScope ps(h, s, t + ".gemm.mlp3");
+            Opt o; o.residual = X; o.c32 = X; o.ldc32 = 256;
+            linear(Lr.mlp3, T, HID, 512, nullptr, 0, XS, 256, o);
+        }
+    }
+    // out[b] = MD0[b, :rowsA] . MD1[b, :rowsW]^T / 16   (MD = projected tokens, "act" storage, image-0 rows then image-1 rows)
+    void similarity(const float* MD, size_t rowsA, size_t rowsW, float* out) const {
+        if (f16) {
+            GemmF16Args g;
+            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+            g.C = out; g.ldc = (int)rowsW; g.M = (int)rowsA; g.N = (int)rowsW; g.K = 256;
+            g.scale = 0.0625f; g.scale_cols = (int)rowsW;
+            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)rowsA * rowsW;
+            launch_gemm_f16x3(g, s);
+        } else {
+            GemmArgs g;
+            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+            g.C = out; g.ldc = (int)rowsW; g.M = (int)rowsA; g.N = (int)rowsW; g.K = 256;
+            g.scale = 0.0625f; g.scale_cols = (int)rowsW;
+            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)rowsA * rowsW;
+            launch_gemm(g, s);
+        }
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
 int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
                   const float* scores0, const float* scores1, const float* size0, const float* size1, int B, int M, int N,
                   int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment, float* sinkhorn_cost,
@@ -1112,104 +1218,26 @@ int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const
     float* UV = h->buf("sg.uv", sinkhorn_work_floats(B, M, N));
     if (!X || !XS || !QKV || !CTX || !HID || !P0 || !SIM || !ST || !UV) return fail(MG_ERR_HIP, "workspace allocation failed");
 
-    // one dispatcher for both arithmetic modes; "act" buffers hold SH8 in f16x3 mode and fp32 otherwise
-    struct Opt { int relu = 0; float scale = 1.f; int scale_cols = 0; const float* residual = nullptr; float* c32 = nullptr; int ldc32 = 0; };
-    auto linear = [&](const LinLayer& L, const float* A, int lda, const float* A1, int lda1, float* act_out, int ld_out, const Opt& o) {
-        if (f16) {
-            GemmF16Args g = lin_args_f16(L, A, lda, (int)T);
-            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
-            g.Cs = act_out; g.ldcs = ld_out; g.C = o.c32; g.ldc = o.ldc32;
-            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
-            launch_gemm_f16x3(g, s);
-        } else {
-            float* out = o.c32 ? o.c32 : act_out;
-            GemmArgs g = lin_args(L, A, lda, (int)T, out, o.c32 ? o.ldc32 : ld_out);
-            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
-            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
-            launch_gemm(g, s);
-        }
-    };
-    float* XA = f16 ? XS : X;  // the GEMM-input view of the descriptor stream
-
+    const GnnRun g{h, s, f16, B, M, N, T0, T, X, XS, QKV, CTX, HID, P0};
     HIPCHK(hipMemcpyAsync(X, desc0, T0 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(X + T0 * 256, desc1, T1 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    {   // keypoint encoder: desc += MLP([x, y, score])  (superglue.py:89-103, :275-276)
+    {
         ProfScope ps(h, s, "sg.kenc");
-        float* KIN = HID;               // (T,32) fp32, then SH8 in place of a second region
-        float* KA = HID + T * 32;
-        launch_sg_kenc_input(kpts0, kpts1, scores0, scores1, size0, size1, B, M, N, KIN, s);
-        const float* a = KIN;
-        if (f16) { launch_to_sh8(KIN, KA, (long long)T * 32, s); a = KA; }
-        Opt relu; relu.relu = 1;
-        linear(h->sg_kenc[0], a, 32, nullptr, 0, P0, 32, relu);
-        linear(h->sg_kenc[1], P0, 32, nullptr, 0, CTX, 64, relu);
-        linear(h->sg_kenc[2], CTX, 64, nullptr, 0, P0, 128, relu);
-        linear(h->sg_kenc[3], P0, 128, nullptr, 0, CTX, 256, relu);
-        Opt last; last.residual = X; last.c32 = X; last.ldc32 = 256;
-        linear(h->sg_kenc[4], CTX, 256, nullptr, 0, XS, 256, last);
+        g.keypoint_encoder(h->sg_kenc, kpts0, kpts1, scores0, scores1, size0, size1);
     }
     if (int rc = tap_copy(h, "sg.kenc", X, T * 256, s)) return rc;
-
     for (int l = 0; l < conf->n_layers; ++l) {
-        const mg_context::SgLayer& Lr = h->sg_gnn[l];
-        const int cross = l & 1;  // GNN_layers = ["self", "cross"] * 9
-        {
-            ProfScope ps(h, s, "sg.gemm.qkv");
-            Opt o; o.scale = f16 ? 0.125f * 1.4426950408889634f : 0.125f; o.scale_cols = 256;  // / sqrt(64) (x log2 e in f16x3 mode)
-            linear(Lr.proj, XA, 256, nullptr, 0, QKV, 768, o);
-        }
-        {
-            ProfScope ps(h, s, cross ? "sg.attn.cross" : "sg.attn.self");
-            if (f16) {
-                AttnF16Args a;
-                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
-                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
-                launch_attention_f16x3(a, s);
-            } else {
-                AttnArgs a;
-                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
-                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
-                launch_attention(a, s);
-            }
-        }
-        {
-            ProfScope ps(h, s, "sg.gemm.mlp0");
-            Opt o; o.relu = 1;
-            linear(Lr.mlp0f, XA, 256, CTX, 256, HID, 512, o);
-        }
-        {
-            ProfScope ps(h, s, "sg.gemm.mlp3");
-            Opt o; o.residual = X; o.c32 = X; o.ldc32 = 256;
-            linear(Lr.mlp3, HID, 512, nullptr, 0, XS, 256, o);
-        }
+        g.layer(h->sg_gnn[l], l & 1, "sg");  // GNN_layers = ["self", "cross"] * 9
         if (int rc = tap_copy(h, "sg.layer" + std::to_string(l), X, T * 256, s)) return rc;
     }
-
     float* MD = QKV;
     {
         ProfScope ps(h, s, "sg.gemm.final_proj");
-        Opt o;
-        linear(h->sg_final, XA, 256, nullptr, 0, MD, 256, o);
+        g.linear(h->sg_final, T, g.xa(), 256, nullptr, 0, MD, 256, GnnRun::Opt());
     }
     {
         ProfScope ps(h, s, "sg.gemm.cost");  // scores / sqrt(256), superglue.py:283-284
-        if (f16) {
-            GemmF16Args g;
-            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
-            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
-            g.scale = 0.0625f; g.scale_cols = N;
-            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
-            launch_gemm_f16x3(g, s);
-        } else {
-            GemmArgs g;
-            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
-            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
-            g.scale = 0.0625f; g.scale_cols = N;
-            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
-            launch_gemm(g, s);
-        }
+        g.similarity(MD, M, N, SIM);
     }
     if (sinkhorn_cost) HIPCHK(hipMemcpyAsync(sinkhorn_cost, SIM, (size_t)B * M * N * sizeof(float), hipMemcpyDeviceToDevice, s));
     {
@@ -1278,84 +1306,27 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
         if (!ENC || !MSG || !LH || !UPD || !LT) return fail(MG_ERR_HIP, "workspace allocation failed");
     }
 
-    // one dispatcher for both arithmetic modes; "act" buffers hold SH8 in f16x3 mode and fp32 otherwise
-    struct Opt { int relu = 0; float scale = 1.f; int scale_cols = 0; const float* residual = nullptr; float* c32 = nullptr; int ldc32 = 0; };
-    auto linear = [&](const LinLayer& L, size_t rows, const float* A, int lda, const float* A1, int lda1, float* act_out, int ld_out, const Opt& o) {
-        if (f16) {
-            GemmF16Args g = lin_args_f16(L, A, lda, (int)rows);
-            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
-            g.Cs = act_out; g.ldcs = ld_out; g.C = o.c32; g.ldc = o.ldc32;
-            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
-            launch_gemm_f16x3(g, s);
-        } else {
-            float* out = o.c32 ? o.c32 : act_out;
-            GemmArgs g = lin_args(L, A, lda, (int)rows, out, o.c32 ? o.ldc32 : ld_out);
-            if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
-            g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;
-            launch_gemm(g, s);
-        }
-    };
-    // MLP([cin->32, 64, 128, 256, 256]) on `rows` input rows of 32 floats; the last layer goes where `last` says
-    auto encoder = [&](const LinLayer* enc, size_t rows, float* in32, float* in_sh8, float* t0, float* t1, float* last_act, const Opt& last) {
-        const float* a = in32;
-        if (f16) { launch_to_sh8(in32, in_sh8, (long long)rows * 32, s); a = in_sh8; }
-        Opt relu; relu.relu = 1;
-        linear(enc[0], rows, a, 32, nullptr, 0, t0, 32, relu);
-        linear(enc[1], rows, t0, 32, nullptr, 0, t1, 64, relu);
-        linear(enc[2], rows, t1, 64, nullptr, 0, t0, 128, relu);
-        linear(enc[3], rows, t0, 128, nullptr, 0, t1, 256, relu);
-        linear(enc[4], rows, t1, 256, nullptr, 0, last_act, 256, last);
-    };
-    float* XA = f16 ? XS : X;  // the GEMM-input view of the descriptor stream
+    const GnnRun g{h, s, f16, B, M, N, T0, T, X, XS, QKV, CTX, HID, P0};
+    using Opt = GnnRun::Opt;
+    float* XA = g.xa();
 
     HIPCHK(hipMemcpyAsync(X, desc0, T0 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipMemcpyAsync(X + T0 * 256, desc1, T1 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    {   // keypoint encoder: desc += MLP([x, y, score])  (gluestick.py:199-200)
+    {
         ProfScope ps(h, s, "gs.kenc");
-        float* KIN = HID;
-        launch_sg_kenc_input(kpts0, kpts1, scores0, scores1, size0, size1, B, M, N, KIN, s);
-        Opt last; last.residual = X; last.c32 = X; last.ldc32 = 256;
-        encoder(h->gs_kenc, T, KIN, HID + T * 32, P0, CTX, XS, last);
+        g.keypoint_encoder(h->gs_kenc, kpts0, kpts1, scores0, scores1, size0, size1);
     }
     if (int rc = tap_copy(h, "gs.kenc", X, T * 256, s)) return rc;
     if (lines) {  // endpoint encodings (gluestick.py:204-212), kept for every line layer
         ProfScope ps(h, s, "gs.lenc");
         float* LIN = LT;  // (E,32) fp32 followed by its SH8 copy
         launch_gs_lenc_input(lines0, lines1, line_scores0, line_scores1, size0, size1, B, n0, n1, LIN, s);
-        Opt last;
-        if (!f16) { last.c32 = ENC; last.ldc32 = 256; }
-        encoder(h->gs_lenc, E, LIN, LIN + E * 32, MSG, LH, ENC, last);
+        g.encoder(h->gs_lenc, E, LIN, LIN + E * 32, MSG, LH, ENC, Opt());
     }
 
     for (int l = 0; l < conf->n_layers; ++l) {
-        const mg_context::SgLayer& Lr = h->gs_gnn[l];
         const int cross = l & 1;  // GNN_layers = ["self", "cross"] * 9
-        {
-            ProfScope ps(h, s, "gs.gemm.qkv");
-            Opt o; o.scale = f16 ? 0.125f * 1.4426950408889634f : 0.125f; o.scale_cols = 256;
-            linear(Lr.proj, T, XA, 256, nullptr, 0, QKV, 768, o);
-        }
-        {
-            ProfScope ps(h, s, cross ? "gs.attn.cross" : "gs.attn.self");
-            if (f16) {
-                AttnF16Args a;
-                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
-                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
-                launch_attention_f16x3(a, s);
-            } else {
-                AttnArgs a;
-                a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
-                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
-                launch_attention(a, s);
-            }
-        }
-        {
-            ProfScope ps(h, s, "gs.gemm.mlp");
-            Opt o; o.relu = 1;
-            linear(Lr.mlp0f, T, XA, 256, CTX, 256, HID, 512, o);
-            Opt r; r.residual = X; r.c32 = X; r.ldc32 = 256;
-            linear(Lr.mlp3, T, HID, 512, nullptr, 0, XS, 256, r);
-        }
+        g.layer(h->gs_gnn[l], cross, "gs");
         if (!cross && lines) {  // line layer after every self layer (gluestick.py:719-741), num_line_iterations = 1
             ProfScope ps(h, s, "gs.line_layer");
             const mg_context::GsLine& Ll = h->gs_line[l / 2];
@@ -1365,34 +1336,14 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
             a.x = XA; a.enc = ENC; a.msg = MSG; a.upd = UPD; a.x32 = X; a.xs = f16 ? XS : nullptr;
             launch_gs_gather_msg(a, s);
             Opt o; o.relu = 1;
-            if (!f16) { o.c32 = LH; o.ldc32 = 512; }
-            linear(Ll.mlp0, E, MSG, 768, nullptr, 0, LH, 512, o);
+            g.linear(Ll.mlp0, E, MSG, 768, nullptr, 0, LH, 512, o);
             Opt u; u.c32 = UPD; u.ldc32 = 256;
-            linear(Ll.mlp3, E, LH, 512, nullptr, 0, nullptr, 0, u);
+            g.linear(Ll.mlp3, E, LH, 512, nullptr, 0, nullptr, 0, u);
             launch_gs_scatter_mean(a, s);
         }
         if (int rc = tap_copy(h, "gs.layer" + std::to_string(l), X, T * 256, s)) return rc;
     }
 
-    auto sim_gemm = [&](const float* MD, size_t rowsA, size_t rowsW, float* out) {  // out[b] = MD0[b,:rowsA] . MD1[b,:rowsW]^T / 16
-        if (f16) {
-            GemmF16Args g;
-            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
-            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = out; g.ldc = (int)rowsW; g.M = (int)rowsA; g.N = (int)rowsW; g.K = 256;
-            g.scale = 0.0625f; g.scale_cols = (int)rowsW;
-            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)rowsA * rowsW;
-            launch_gemm_f16x3(g, s);
-        } else {
-            GemmArgs g;
-            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
-            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = out; g.ldc = (int)rowsW; g.M = (int)rowsA; g.N = (int)rowsW; g.K = 256;
-            g.scale = 0.0625f; g.scale_cols = (int)rowsW;
-            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)rowsA * rowsW;
-            launch_gemm(g, s);
-        }
-    };
     auto assign = [&](const float* scores, float bin, int m, int n, float* la, int64_t* mt0, int64_t* mt1, float* sc0, float* sc1) {
         const size_t r0 = (size_t)B * m, r1 = (size_t)B * n;
         GsSoftmaxArgs d;
@@ -1411,10 +1362,8 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
     float* MD = QKV;
     {
         ProfScope ps(h, s, "gs.match");
-        Opt o;
-        if (!f16) { o.c32 = MD; o.ldc32 = 256; }
-        linear(h->gs_final, T, XA, 256, nullptr, 0, MD, 256, o);
-        sim_gemm(MD, M, N, SIM);
+        g.linear(h->gs_final, T, XA, 256, nullptr, 0, MD, 256, Opt());
+        g.similarity(MD, M, N, SIM);
         assign(SIM, h->gs_bin, M, N, log_assignment, matches0, matches1, mscores0, mscores1);
     }
     if (lines) {
@@ -1422,10 +1371,8 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
         float* JS = h->buf("gs.js", (size_t)B * 4 * n0 * n1);
         float* RAW = raw_line_scores ? raw_line_scores : h->buf("gs.raw", (size_t)B * n0 * n1);
         if (!JS || !RAW) return fail(MG_ERR_HIP, "workspace allocation failed");
-        Opt o;
-        if (!f16) { o.c32 = MD; o.ldc32 = 256; }
-        linear(h->gs_final_line, T, XA, 256, nullptr, 0, MD, 256, o);  // all tokens; only the leading 2*n rows of a pair are used
-        sim_gemm(MD, 2 * (size_t)n0, 2 * (size_t)n1, JS);
+        g.linear(h->gs_final_line, T, XA, 256, nullptr, 0, MD, 256, Opt());  // all tokens; only the leading 2*n rows of a pair are used
+        g.similarity(MD, 2 * (size_t)n0, 2 * (size_t)n1, JS);
         launch_gs_line_scores(JS, reinterpret_cast<const long long*>(junc_idx0), reinterpret_cast<const long long*>(junc_idx1), B, n0, n1, RAW, s);
         assign(RAW, h->gs_line_bin, n0, n1, line_log_assignment, line_matches0, line_matches1, line_mscores0, line_mscores1);
     }
