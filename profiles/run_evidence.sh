@@ -25,6 +25,9 @@ w=$(find "$out/pmc_${tag}_WRITE_SIZE" -name "*counter_collection.csv" | head -1)
 python3 profiles/summarize_pmc.py "$f" "$w" "$out/${tag}_f16x3_hbm_traffic.json" > /dev/null
 rm -rf "$out"/pmc_${tag}_* "$out"/prof_${tag}_*
 profiles/run_mfma_pmc.sh "$tag" > "$out/${tag}_mfma_summary.txt" 2>&1 || true
+for m in mfma_peak bw_pattern; do  # micro-benchmarks are built on demand (the binaries are not tracked)
+    [ -x tests/micro/$m ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -Wno-unused-result -o tests/micro/$m tests/micro/$m.hip
+done
 (tests/micro/mfma_peak; tests/micro/bw_pattern) > "$out/${tag}_micro.txt" 2>&1 || true
 cat "$out/${tag}_micro.txt"
 cat "$out/${tag}_trace_summary.txt"
