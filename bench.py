@@ -6,16 +6,26 @@
 
 Workload = BASELINE.json config 2: 640x480 gray images, 1024 keypoints, 32 pairs per GPU per step
 (weak scaling: every rank runs its own 32 pairs; the only collective is one RCCL all-gather of the
-match outputs per step).  Inputs are synthetic (seeded smooth noise) and resident in HBM before the
-timed region; weights are seeded (there are no checkpoints offline).  One "step" = one pass of the
-hot path over one batch: extractor on 2B images, matcher on B pairs, all-gather.
+match outputs per step).  Inputs are synthetic and resident in HBM before the timed region: SURVEY 8(d)'s
+tiling of the boat pair (the reference's test asset, carried by tests/golden/two_view_boat.npz) resized to
+the workload size with per-item circular shifts; `--images noise` gives seeded smooth noise instead.
+Weights are seeded (there are no checkpoints offline).  One "step" = one pass of the hot path over one
+batch: extractor on 2B images, matcher on B pairs, all-gather.
+
+`--gpus N` without a launcher (no WORLD_SIZE in the environment) starts the N ranks itself, one child
+process per device, before the parent makes any HIP call (the pattern of gluefactory/train.py:699-701);
+under `torch.distributed.run` the ranks are already there.  It never reports fewer GPUs than asked for.
 
 Rank 0 prints ONE JSON line with the contract fields plus `roofline` (dominant kernel, HIP-event
-timed inside the timed region) and, at N == 1, `cpu_baseline` (the CPU oracle on a bounded sample).
+timed inside the timed region), `f32_mode` (the same workload on the fp32-input MFMA path, timed in the
+same run) and, at N == 1, `cpu_baseline` (the CPU oracle, SURVEY 8(d) protocol, on a bounded sample).
 """
 import argparse
 import json
 import os
+import socket
+import statistics
+import subprocess
 import sys
 import time
 
@@ -34,6 +44,30 @@ H, W, K, PAIRS = 480, 640, 1024, 32
 SUSTAINED = {"f32": None, "f16x3": 1668.0}
 PEAK = {"f32": 157.3,      # v_mfma_f32_32x32x2_f32
         "f16x3": 2500.0}   # v_mfma_f32_32x32x16_f16; every algorithmic product costs 3 MFMA products (hi.hi + hi.lo + lo.hi)
+
+
+def boat_images(n, seed):
+    """boat1 / boat2 resized bilinearly to the workload size, tiled over the batch with per-item integer
+    circular shifts (natural image statistics).  Even items come from boat1, odd items from boat2."""
+    import numpy as np
+
+    z = np.load(os.path.join(ROOT, "tests", "golden", "two_view_boat.npz"))
+    g = torch.Generator().manual_seed(seed)
+    base = [torch.nn.functional.interpolate(torch.from_numpy(z[k]).float()[None, None] / 255.0, size=(H, W), mode="bilinear", align_corners=False)[0, 0]
+            for k in ("gray0", "gray1")]
+    out = torch.empty(n, 1, H, W)
+    for i in range(n):
+        dy, dx = (int(v) for v in torch.randint(0, 10 ** 6, (2,), generator=g))
+        out[i, 0] = torch.roll(base[i & 1], shifts=(dy % H, dx % W), dims=(0, 1))
+    return out.contiguous()
+
+
+def make_images(kind, n_pairs, seed):
+    """(2*n_pairs, 1, H, W): the view-0 images of all pairs, then the view-1 images."""
+    if kind == "noise":
+        return synthetic_images(2 * n_pairs, seed)
+    im = boat_images(2 * n_pairs, seed)  # item 2i = boat1 shifted, 2i+1 = boat2 shifted -> pair i = (2i, 2i+1)
+    return torch.cat([im[0::2], im[1::2]], 0).contiguous()
 
 
 def synthetic_images(n, seed):
@@ -78,36 +112,104 @@ def algorithmic_flops(B):
     return f
 
 
-def cpu_baseline(pairs=4, matcher="lightglue"):
-    """The CPU oracle (oracle/sp_lg_oracle.py, a restatement of the reference) on a bounded sample."""
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(matcher="lightglue", images="boat", budget_s=75.0):
+    """The CPU oracle (oracle/sp_lg_oracle.py, a restatement of the reference) on a bounded sample of the same workload,
+    SURVEY 8(d) protocol: B = 1 and B = 8, 3 warm-up + >= 10 timed repetitions each, time.perf_counter, median; all
+    cores this process may use.  A repetition count is cut (and said so in `sample`) only if the leg would pass `budget_s`."""
     from oracle import sp_lg_oracle as O
 
     torch.set_grad_enabled(False)
-    # the GPU box gives one GPU a 16-core CPU share; more threads than that only oversubscribe it
-    cores = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     torch.set_num_threads(cores)
     W_sp = O.make_sp_weights(0)
     if matcher == "gluestick":
         return None  # secondary workload: its line inputs are built from the GPU run's keypoints
     W_lg = O.make_lg_weights(7, final_gain=8.0, match_bias=2.0) if matcher == "lightglue" else O.make_sg_weights(9)
-    im = synthetic_images(2 * pairs, 123)
-    size = torch.tensor([[float(W), float(H)]])
     spc = dict(nms_radius=3, detection_threshold=0.0, max_num_keypoints=K)
-    t0 = time.perf_counter()
-    n = 0
-    while n < pairs or (time.perf_counter() - t0 < 10.0 and n < 64):
-        i = n % pairs
-        data = {"view0": {"image": im[2 * i: 2 * i + 1], "image_size": size}, "view1": {"image": im[2 * i + 1: 2 * i + 2], "image_size": size}}
-        if matcher == "lightglue":
-            O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1))
-        else:
-            p0, p1 = O.superpoint_forward(data["view0"], W_sp, **spc), O.superpoint_forward(data["view1"], W_sp, **spc)
-            O.superglue_forward({**{k + "0": v for k, v in p0.items()}, **{k + "1": v for k, v in p1.items()}, **data}, W_lg)
-        n += 1
-    dt = time.perf_counter() - t0
-    pairs = n
-    return {"value": round(pairs / dt, 4), "unit": "pairs/s", "cores": cores, "kind": "port",
-            "sample": f"{pairs} pairs of the same workload ({W}x{H}, {K} kpts), batch 1, {dt:.1f} s of CPU time"}
+
+    def run(batch):
+        im = make_images(images, batch, 123)
+        size = torch.tensor([[float(W), float(H)]] * batch)
+        data = {"view0": {"image": im[:batch], "image_size": size}, "view1": {"image": im[batch:], "image_size": size}}
+
+        def once():
+            if matcher == "lightglue":
+                O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1))
+            else:
+                p0, p1 = O.superpoint_forward(data["view0"], W_sp, **spc), O.superpoint_forward(data["view1"], W_sp, **spc)
+                O.superglue_forward({**{k + "0": v for k, v in p0.items()}, **{k + "1": v for k, v in p1.items()}, **data}, W_lg)
+
+        t_leg = time.perf_counter()
+        warm = 0
+        for _ in range(3):
+            once()
+            warm += 1
+            if time.perf_counter() - t_leg > budget_s / 4:
+                break
+        times = []
+        while len(times) < 10:
+            t0 = time.perf_counter()
+            once()
+            times.append(time.perf_counter() - t0)
+            if time.perf_counter() - t_leg > budget_s and len(times) >= 3:
+                break
+        med = statistics.median(times)
+        return {"batch": batch, "pairs_per_s": round(batch / med, 4), "median_s": round(med, 4), "reps": len(times), "warmup": warm}
+
+    legs = [run(1), run(8)]
+    best = max(legs, key=lambda l: l["pairs_per_s"])
+    return {"value": best["pairs_per_s"], "unit": "pairs/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+            "protocol": "median of timed repetitions after warm-up, torch.set_num_threads(cores), time.perf_counter",
+            "legs": legs,
+            "sample": (f"same workload ({W}x{H}, {K} kpts, {images} images): batch 1 x {legs[0]['reps']} reps and batch 8 x {legs[1]['reps']} reps "
+                       f"({legs[0]['warmup']} / {legs[1]['warmup']} warm-up); value = the faster batch size ({best['batch']})")}
+
+
+def launch_ranks(args):
+    """Parent of a stand-alone `--gpus N` run: start one rank per device and relay rank 0's JSON line.
+
+    Nothing here touches HIP (`device_count` does not initialise the runtime on this image), so the children are
+    ordinary fresh processes -- no exec of a process that owns a GPU context."""
+    n_dev = torch.cuda.device_count()
+    if n_dev < args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} was asked for but {n_dev} HIP device(s) are visible; refusing to report a smaller run")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(args.gpus):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(args.gpus), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        pending = set(range(args.gpus))
+        while pending:
+            for r in sorted(pending):
+                code = procs[r].poll()
+                if code is None:
+                    continue
+                pending.discard(r)
+                if code != 0:
+                    rc = rc or code
+                    for q in pending:  # one rank failed: the others would wait in a collective forever
+                        procs[q].terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    raise SystemExit(rc)
 
 
 def main():
@@ -126,15 +228,24 @@ def main():
     ap.add_argument("--lines", type=int, default=250, help="line segments per image (gluestick)")
     ap.add_argument("--kpts", type=int, default=K, help="keypoints per image")
     ap.add_argument("--size", default=f"{W}x{H}", help="image WxH (default 640x480 = configs[1]; 1024x1024 with --kpts 2048 = the per-GPU share of configs[2])")
+    ap.add_argument("--images", default="boat", choices=["boat", "noise"],
+                    help="boat: SURVEY 8(d) tiling of the boat pair with circular shifts (default); noise: seeded smooth noise")
+    ap.add_argument("--no-f32", action="store_true", help="skip the f32-mode sibling measurement")
     args = ap.parse_args()
     K = args.kpts
     W, H = (int(v) for v in args.size.lower().split("x"))
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        launch_ranks(args)  # does not return
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}; refusing to report a run of another size")
+    if not torch.cuda.is_available() or torch.cuda.device_count() <= local_rank:
+        raise SystemExit(f"bench.py: rank {rank} has no HIP device {local_rank} (the hot path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -146,21 +257,27 @@ def main():
 
     torch.set_grad_enabled(False)
     B = args.pairs
-    pipe = TwoViewPipeline({
-        "extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": K, "nms_radius": 3,
-                      "detection_threshold": 0.0, "remove_borders": 4, "force_num_keypoints": True, "sync_free": True,
-                      "precision": args.precision},
-        "matcher": {"lightglue": {"name": "matchers.lightglue", "filter_threshold": 0.1, "precision": args.precision},
-                    "superglue": {"name": "gluefactory_nonfree.superglue", "filter_threshold": 0.2, "precision": args.precision,
-                                  "return_log_assignment": False},
-                    "gluestick": {"name": "matchers.gluestick", "filter_threshold": 0.2, "precision": args.precision,
-                                  "return_log_assignment": False}}[args.matcher],
-    }).eval()
-    pipe.extractor.load_state_dict(O.make_sp_weights(0))
-    pipe.matcher.load_state_dict({"lightglue": lambda: O.make_lg_weights(7, final_gain=8.0, match_bias=2.0),
-                                  "superglue": lambda: O.make_sg_weights(9), "gluestick": lambda: O.make_gs_weights(4)}[args.matcher]())
+    W_sp = O.make_sp_weights(0)
+    W_m = {"lightglue": lambda: O.make_lg_weights(7, final_gain=8.0, match_bias=2.0),
+           "superglue": lambda: O.make_sg_weights(9), "gluestick": lambda: O.make_gs_weights(4)}[args.matcher]()
 
-    im = synthetic_images(2 * B, 1000 + rank).to(dev)
+    def build_pipe(precision):
+        pp = TwoViewPipeline({
+            "extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": K, "nms_radius": 3,
+                          "detection_threshold": 0.0, "remove_borders": 4, "force_num_keypoints": True, "precision": precision},
+            "matcher": {"lightglue": {"name": "matchers.lightglue", "filter_threshold": 0.1, "precision": precision},
+                        "superglue": {"name": "gluefactory_nonfree.superglue", "filter_threshold": 0.2, "precision": precision,
+                                      "return_log_assignment": False},
+                        "gluestick": {"name": "matchers.gluestick", "filter_threshold": 0.2, "precision": precision,
+                                      "return_log_assignment": False}}[args.matcher],
+        }).eval()
+        pp.extractor.load_state_dict(W_sp)
+        pp.matcher.load_state_dict(W_m)
+        return pp
+
+    pipe = build_pipe(args.precision)
+
+    im = make_images(args.images, B, 1000 + rank).to(dev)
     size = torch.tensor([[float(W), float(H)]] * B, device=dev)
     data = {"view0": {"image": im[:B], "image_size": size}, "view1": {"image": im[B:], "image_size": size}}
 
@@ -178,9 +295,11 @@ def main():
             data["lines" + side] = torch.gather(kps, 1, idx.reshape(B, 2 * n)[..., None].expand(-1, -1, 2)).reshape(B, n, 2, 2)
             data["line_scores" + side] = torch.rand(B, n, generator=g).to(dev)
 
+    gather_stats = {}
+
     def step():
         pred = pipe(data)
-        return all_gather_matches(pred) if world > 1 else pred
+        return all_gather_matches(pred, num_pairs=world * B, stats=gather_stats) if world > 1 else pred
 
     def note(msg):
         if rank == 0:
@@ -220,6 +339,35 @@ def main():
             acc[0] += ms
             acc[1] += 1
         e.profile_enable(False)
+
+    # the same workload on the fp32-input MFMA path (the reference's arithmetic), timed the same way in the same run
+    f32_mode = None
+    if args.precision == "f16x3" and not args.no_f32:
+        del out
+        pipe32 = build_pipe("f32")
+        n32 = max(2, min(args.steps, 3))
+        pipe32(data)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n32):
+            p32 = pipe32(data)
+            if world > 1:
+                all_gather_matches(p32, num_pairs=world * B)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt32 = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt32], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt32 = float(t.item())
+        f32_mode = {"value": round(world * B * n32 / dt32, 3), "unit": "pairs/s", "dtype": "f32", "steps": n32, "warmup": 1,
+                    "ms_per_step": round(dt32 / n32 * 1e3, 3), "peak": PEAK["f32"],
+                    "arithmetic": "fp32 storage, fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate"}
+        note(f"f32 mode: {f32_mode['ms_per_step']:.2f} ms/step")
+        del pipe32, p32
 
     if rank == 0:
         flops = algorithmic_flops(B)
@@ -262,7 +410,11 @@ def main():
                                     if args.matcher == "superglue" else
                                     f"SuperPoint + GlueStick, {W}x{H}, {K} kpts + {args.lines} synthetic segments, batch={B} pairs per GPU "
                                     "(BASELINE.json configs[4]; LSD itself is a CPU dependency and not timed)"),
-                       "pairs_per_gpu": B, "global_pairs": B * world, "parallelism": f"dp{world}", "matches_per_step_rank0": nvalid,
+                       "pairs_per_gpu": B, "pairs_per_rank": [B] * world, "global_pairs": B * world, "parallelism": f"dp{world}",
+                       "images": args.images, "matches_per_step_rank0": nvalid,
+                       "all_gather": ({"collective": "all_gather_into_tensor (RCCL)", "calls_per_step": 1,
+                                       "bytes_sent_per_rank": gather_stats.get("bytes_sent"), "bytes_received_per_rank": gather_stats.get("bytes_received")}
+                                      if world > 1 else None),
                        "arithmetic": ("fp32 storage, fp32-input MFMA, fp32 accumulate" if args.precision == "f32" else
                                       "fp32-equivalent split-fp16 storage (hi+lo), f16 MFMA x3 products, fp32 accumulate")},
             "roofline": {"bound": "mfma", "kernel": dom, "achieved": round(achieved, 2), "peak": PEAK[args.precision], "unit": "TFLOP/s",
@@ -285,9 +437,11 @@ def main():
                                      "peak": PEAK[args.precision], "unit": "TFLOP/s", "executed_frac": round(a_tf * mult / PEAK[args.precision], 4),
                                      "executed_frac_of_sustained": (round(a_tf * mult / SUSTAINED[args.precision], 4) if SUSTAINED[args.precision] else None),
                                      "ms_per_step": round(a_ms / args.steps, 4)}
+        if f32_mode is not None:
+            res["f32_mode"] = f32_mode
         if world == 1 and not args.no_cpu_baseline:
-            note("timing the CPU oracle on a bounded sample (10-30 s)")
-            cb = cpu_baseline(matcher=args.matcher)
+            note("timing the CPU oracle (B = 1 and B = 8, 3 warm-up + 10 repetitions each, about 1.5 min)")
+            cb = cpu_baseline(matcher=args.matcher, images=args.images)
             if cb is not None:
                 res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)

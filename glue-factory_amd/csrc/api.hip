@@ -94,7 +94,8 @@ struct mg_context {
     int device = 0;
     int precision = MG_PREC_F16X3;
     std::map<std::string, HostTensor> raw[4];
-    std::vector<void*> owned;  // device allocations of prepared weights
+    std::vector<void*> owned[5];  // device allocations of prepared weights, per model (`which`; 4 = mg_test_* scratch)
+    int cur_which = 0;            // the model whose weights are being prepared (upload() books into owned[cur_which])
 
     // SuperPoint
     int sp_variant = -1;
@@ -176,8 +177,19 @@ int upload(mg_context* h, const std::vector<float>& v, float** out) {
     void* p = nullptr;
     HIPCHK(hipMalloc(&p, v.size() * sizeof(float)));
     HIPCHK(hipMemcpy(p, v.data(), v.size() * sizeof(float), hipMemcpyHostToDevice));
-    h->owned.push_back(p);
+    h->owned[h->cur_which].push_back(p);
     *out = static_cast<float*>(p);
+    return 0;
+}
+
+// Re-tiling after a new load_state_dict: the previous device copies of that model are released first (after a device
+// sync: launches of the old weights may still be in flight on some stream).
+int begin_prepare(mg_context* h, int which) {
+    h->cur_which = which;
+    if (h->owned[which].empty()) return 0;
+    HIPCHK(hipDeviceSynchronize());
+    for (void* q : h->owned[which]) (void)hipFree(q);
+    h->owned[which].clear();
     return 0;
 }
 
@@ -291,6 +303,8 @@ int prep_bn(mg_context* h, const std::string& prefix, int C, float** ps, float**
 
 int prepare_sp(mg_context* h, int variant) {
     if (h->sp_variant == variant) return 0;
+    h->sp_variant = -1;
+    if (int rc = begin_prepare(h, 0)) return rc;
     const int cin[9] = {64, 64, 64, 64, 128, 128, 128, 128, 128};
     const int cout[9] = {64, 64, 64, 128, 128, 128, 128, 256, 256};
     if (variant == MG_SP_MAGICLEAP) {
@@ -377,6 +391,8 @@ int prep_ffn(mg_context* h, const std::string& p, LgBlock* blk) {
 
 int prepare_lg(mg_context* h, int n_layers) {
     if (h->lg_layers == n_layers) return 0;
+    h->lg_layers = -1;
+    if (int rc = begin_prepare(h, 1)) return rc;
     h->lg_self.assign(n_layers, LgBlock());
     h->lg_cross.assign(n_layers, LgBlock());
     for (int i = 0; i < n_layers; ++i) {
@@ -543,6 +559,8 @@ int sg_prep_layer(mg_context* h, int which, const std::string& p, mg_context::Sg
 
 int prepare_sg(mg_context* h, int n_layers) {
     if (h->sg_layers == n_layers) return 0;
+    h->sg_layers = -1;
+    if (int rc = begin_prepare(h, 2)) return rc;
     if (int rc = sg_prep_encoder(h, 2, "kenc.encoder", 3, h->sg_kenc)) return rc;
     h->sg_gnn.assign(n_layers, mg_context::SgLayer());
     for (int l = 0; l < n_layers; ++l)
@@ -559,6 +577,8 @@ int prepare_sg(mg_context* h, int n_layers) {
 // endpoint encoder, one line layer per self layer (MLP([768, 512, 256]) with BatchNorm), two final projections.
 int prepare_gs(mg_context* h, int n_layers) {
     if (h->gs_layers == n_layers) return 0;
+    h->gs_layers = -1;
+    if (int rc = begin_prepare(h, 3)) return rc;
     if (int rc = sg_prep_encoder(h, 3, "kenc.encoder", 3, h->gs_kenc)) return rc;
     if (int rc = sg_prep_encoder(h, 3, "lenc.encoder", 5, h->gs_lenc)) return rc;
     h->gs_gnn.assign(n_layers, mg_context::SgLayer());
@@ -675,7 +695,8 @@ int mg_destroy(mg_handle h) {
     if (!h) return 0;
     (void)hipSetDevice(h->device);
     (void)hipDeviceSynchronize();
-    for (void* p : h->owned) (void)hipFree(p);
+    for (auto& v : h->owned)
+        for (void* p : v) (void)hipFree(p);
     for (auto& kv : h->ws) kv.second.release();
     for (auto& kv : h->taps) kv.second.release();
     for (auto e : h->event_pool) (void)hipEventDestroy(e);
@@ -1448,6 +1469,7 @@ int mg_nn_forward(mg_handle h, const mg_nn_conf* conf, const float* desc0, const
 int mg_test_linear(mg_handle h, const float* A, const float* W_host, const float* bias_host, int M, int N, int K, float* C, void* stream) {
     if (!h || !A || !W_host || !C || M < 1 || N < 1 || K < 32 || (K % 32)) return fail(MG_ERR_ARG, "bad argument (K must be a multiple of 32)");
     HIPCHK(hipSetDevice(h->device));
+    if (int rc = begin_prepare(h, 4)) return rc;
     LinLayer L;
     std::vector<const float*> rows(N);
     for (int n = 0; n < N; ++n) rows[n] = W_host + (size_t)n * K;

@@ -55,7 +55,11 @@ def merge_conf(*confs):
 
 
 class WeightTree(nn.Module):
-    """Nested container of buffers addressed by dotted reference keys."""
+    """Nested container of buffers addressed by dotted reference keys.
+
+    The owner (`NativeModel`) emits and ingests these tensors under the reference's key names itself, so the
+    tree takes no part in `nn.Module.load_state_dict`'s recursion (its keys would carry a `weights.` infix).
+    """
 
     def set(self, key, tensor):
         head, _, rest = key.partition(".")
@@ -68,6 +72,9 @@ class WeightTree(nn.Module):
         if head not in self._modules:
             self.add_module(head, WeightTree())
         self._modules[head].set(rest, tensor)
+
+    def _load_from_state_dict(self, *args, **kwargs):
+        return
 
 
 class BaseModel(nn.Module):
@@ -119,6 +126,12 @@ class BaseModel(nn.Module):
     def loss(self, pred, data):
         raise NotImplementedError
 
+    def load_state_dict(self, *args, **kwargs):
+        """base_model.py:132-136: load, then mark the model (and its BaseModel children) initialized."""
+        ret = super().load_state_dict(*args, **kwargs)
+        self.set_initialized()
+        return ret
+
     def is_initialized(self):
         ok = True
         for _, child in self.named_children():
@@ -149,6 +162,10 @@ class NativeModel(BaseModel):
         self._uploaded_version = -1
         self._weights_version = 0
         self.weights = WeightTree()
+        # One empty parameter while no weights are loaded: the reference's composite counts the *parameters* of foreign
+        # children to decide `is_initialized()` (base_model.py:138-151, guard eval/io.py:92-96); it disappears with the
+        # first successful load, so a pipeline built without `weights:` is rejected there instead of at the first forward.
+        self.weights_not_loaded = nn.Parameter(torch.zeros(0), requires_grad=False)
         path = conf.get("weights")
         if path:
             import os
@@ -160,22 +177,55 @@ class NativeModel(BaseModel):
                 )
             self.load_state_dict(torch.load(str(path), map_location="cpu"))
 
-    def load_state_dict(self, state_dict, strict=False, **kw):
-        sd = self._rename_keys(dict(state_dict))
-        n = 0
+    # Loading composes with nn.Module's recursion: a composite (this package's TwoViewPipeline or the reference's own,
+    # gluefactory/models/two_view_pipeline.py) calls `_load_from_state_dict` of every child with the child's prefix --
+    # the reference's checkpoint path, utils/experiments.py:90 `model.load_state_dict(ckpt["model"], strict=False)`.
+    def _ingest(self, sd):
+        """Take the tensors this model needs out of a (prefix-free) state_dict; returns (loaded, unexpected) key lists."""
+        sd = self._rename_keys(dict(sd))
+        loaded, unexpected = [], []
         for k, v in sd.items():
+            if k == "weights_not_loaded":
+                continue
+            if k.startswith("weights."):  # a state_dict written through the plain nn.Module path of an older build
+                k = k[len("weights."):]
             if torch.is_tensor(v) and v.dtype.is_floating_point and self._wants(k):
                 self.weights.set(k, v.detach().clone().float())
-                n += 1
-        if n == 0:
+                loaded.append(k)
+            elif torch.is_tensor(v) and v.dtype.is_floating_point:
+                unexpected.append(k)
+        if loaded:
+            self._weights_version += 1
+            self._parameters.pop("weights_not_loaded", None)
+            self.are_weights_initialized = True
+        return loaded, unexpected
+
+    def _load_from_state_dict(self, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        own = {k[len(prefix):]: v for k, v in state_dict.items() if k.startswith(prefix)}
+        had = set(self.weights.state_dict())
+        loaded, unexpected = self._ingest(own)
+        if strict:
+            unexpected_keys.extend(prefix + k for k in unexpected)
+            missing = sorted(had - set(loaded)) if had else ([] if loaded else ["*"])
+            missing_keys.extend(prefix + k for k in missing)
+
+    def load_state_dict(self, state_dict, strict=False, **kw):
+        had = set(self.weights.state_dict())
+        loaded, unexpected = self._ingest(state_dict)
+        if not loaded:
             raise RuntimeError("state_dict holds none of the tensors this model needs")
-        self._weights_version += 1
-        self.set_initialized()
-        return None
+        missing = sorted(had - set(loaded))
+        if strict and (missing or unexpected):
+            raise RuntimeError(f"load_state_dict(strict=True): missing {missing}, unexpected {unexpected}")
+        from torch.nn.modules.module import _IncompatibleKeys
+
+        return _IncompatibleKeys(missing, unexpected)
 
     def state_dict(self, *a, **kw):
-        sd = self.weights.state_dict(*a, **kw)
-        return sd
+        return self.weights.state_dict(*a, **kw)
+
+    def is_initialized(self):
+        return bool(self.are_weights_initialized) and len(self.weights._modules) + len(self.weights._buffers) > 0
 
     def _rename_keys(self, sd):
         return sd

@@ -38,32 +38,56 @@ def shard_batch(data, rank, world_size):
     return cut(data)
 
 
-def all_gather_matches(pred, group=None, with_keypoints=False, force=False):
-    """All-gather the match outputs of every rank (equal shard sizes) -> full-batch tensors on all ranks.
+def all_gather_matches(pred, group=None, with_keypoints=False, force=False, num_pairs=None, stats=None):
+    """All-gather the match outputs of every rank -> full-batch tensors (pair order = rank order) on all ranks.
 
-    One packed buffer per rank -> a single all_gather_into_tensor call.  `force` runs the collective even in a
-    one-rank group (used by the single-GPU test of the RCCL path).
+    One packed buffer per rank -> a single `all_gather_into_tensor` call.  Shards may differ in size
+    (`shard_range` hands out blocks that differ by one pair when B % world != 0): every rank pads its buffer to the
+    largest shard and the padding rows are dropped on return.  The shard sizes come from `num_pairs` (the global
+    batch, split by `shard_range`) when given -- no extra traffic -- and from one tiny all-gather of the local row
+    counts otherwise.  `force` runs the collective even in a one-rank group (the single-GPU test of the RCCL path).
+    `stats`, if a dict, receives `bytes_sent` / `bytes_received` of this call.
     """
-    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
-        return {k: pred[k] for k in GATHER_KEYS + (OPTIONAL_KEYS if with_keypoints else ()) if k in pred}
-    world = dist.get_world_size(group)
     keys = [k for k in GATHER_KEYS + (OPTIONAL_KEYS if with_keypoints else ()) if k in pred]
+    if not dist.is_available() or not dist.is_initialized() or (dist.get_world_size(group) == 1 and not force):
+        if stats is not None:
+            stats.update(bytes_sent=0, bytes_received=0)
+        return {k: pred[k] for k in keys}
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
     parts, meta = [], []
     for k in keys:
         t = pred[k]
         if t.dtype == torch.int64:
-            w = t.to(torch.int32).view(torch.float32) if t.is_contiguous() else t.contiguous().to(torch.int32).view(torch.float32)
+            w = t.contiguous().to(torch.int32).view(torch.float32)
         else:
             w = t.float()
         meta.append((k, t.shape, t.dtype))
         parts.append(w.reshape(t.shape[0], -1))
     packed = torch.cat(parts, 1).contiguous()  # (b_local, F) fp32 words
-    out = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=packed.device)
-    dist.all_gather_into_tensor(out.view(-1, packed.shape[1]), packed, group=group)
-    out = out.view(world * packed.shape[0], -1)
+    b_local, F = packed.shape
+    if num_pairs is not None:
+        counts = [hi - lo for lo, hi in (shard_range(num_pairs, r, world) for r in range(world))]
+        if counts[rank] != b_local:
+            raise ValueError(f"rank {rank} holds {b_local} pairs but shard_range({num_pairs}, {rank}, {world}) gives {counts[rank]}")
+    else:
+        c = torch.tensor([b_local], dtype=torch.int64, device=packed.device)
+        cs = torch.empty(world, dtype=torch.int64, device=packed.device)
+        dist.all_gather_into_tensor(cs, c, group=group)
+        counts = [int(v) for v in cs.tolist()]
+    b_max = max(counts)
+    if b_local < b_max:  # equal send counts are required by the collective (RCCL: undefined behaviour otherwise)
+        packed = torch.cat([packed, packed.new_zeros(b_max - b_local, F)], 0)
+    out = torch.empty((world * b_max, F), dtype=packed.dtype, device=packed.device)
+    dist.all_gather_into_tensor(out, packed, group=group)
+    if stats is not None:
+        stats.update(bytes_sent=packed.numel() * 4, bytes_received=out.numel() * 4)
+    if min(counts) != b_max:
+        out = torch.cat([out[r * b_max: r * b_max + n] for r, n in enumerate(counts)], 0)
     res, col = {}, 0
     for k, shape, dtype in meta:
-        f = int(torch.tensor(shape[1:]).prod()) if len(shape) > 1 else 1
+        f = 1
+        for d in shape[1:]:
+            f *= int(d)
         chunk = out[:, col: col + f]
         col += f
         if dtype == torch.int64:

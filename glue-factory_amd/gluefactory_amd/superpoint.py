@@ -78,19 +78,18 @@ class SuperPoint(NativeModel):
         kp, sc, ds, nv, heat, dense = eng.sp_forward(
             nc, image, data.get("image_size"), want_heatmap=self._wants_heatmap(), want_dense=bool(self.conf.dense_outputs)
         )
-        if not self.conf.get("sync_free", False):
+        # `force_num_keypoints` keeps K rows per image whatever was detected (the reference pads to K, :304-317), so
+        # nothing depends on the counts and the forward stays free of host synchronisation
+        if not self.conf.force_num_keypoints and not self.conf.get("sync_free", False):
             counts = nv.cpu()
             n_min = int(counts.min())
             if n_min < nc.max_num_keypoints:
-                if image.shape[0] == 1:
-                    kp, sc, ds = kp[:, :n_min], sc[:, :n_min], ds[:, :n_min]
-                elif not self.conf.force_num_keypoints and int(counts.max()) != n_min:
+                if image.shape[0] > 1 and int(counts.max()) != n_min:
                     raise RuntimeError(
                         f"images of one batch produced different keypoint counts {counts.tolist()} "
                         "(the reference cannot stack them either, superpoint.py:319-320); set force_num_keypoints"
                     )
-                elif not self.conf.force_num_keypoints:
-                    kp, sc, ds = kp[:, :n_min], sc[:, :n_min], ds[:, :n_min]
+                kp, sc, ds = kp[:, :n_min], sc[:, :n_min], ds[:, :n_min]
         pred = {"keypoints": kp, "keypoint_scores": sc, "descriptors": ds}
         if self.conf.dense_outputs:
             pred["dense_descriptors"] = dense

@@ -18,9 +18,13 @@ def pytest_configure(config):
 
 
 def pytest_collection_modifyitems(config, items):
-    # `-m gpu` on a box without a GPU is a hard error, not a silent skip
     if torch.cuda.is_available():
         return
+    # `-m gpu` on a box without a GPU is a hard error, not a silent skip (a green run that tested nothing);
+    # an unfiltered run on a CPU box skips the GPU tests
+    expr = (config.getoption("markexpr", "") or "").replace(" ", "")
+    if "gpu" in expr and "notgpu" not in expr:
+        pytest.exit("`-m gpu` was selected but no HIP device is visible: the GPU parity tests cannot run here", returncode=3)
     skip = pytest.mark.skip(reason="no GPU visible")
     for item in items:
         if "gpu" in item.keywords:

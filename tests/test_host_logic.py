@@ -113,7 +113,7 @@ def _free_port():
     return p
 
 
-def _gather_worker(rank, world, port, out):
+def _gather_worker(rank, world, port, n_pairs, out):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -121,26 +121,84 @@ def _gather_worker(rank, world, port, out):
 
     g = torch.Generator().manual_seed(0)
     full = {
-        "matches0": torch.randint(-1, 50, (4, 9), generator=g),
-        "matches1": torch.randint(-1, 50, (4, 7), generator=g),
-        "matching_scores0": torch.rand(4, 9, generator=g),
-        "matching_scores1": torch.rand(4, 7, generator=g),
-        "keypoints0": torch.rand(4, 9, 2, generator=g),
+        "matches0": torch.randint(-1, 50, (n_pairs, 9), generator=g),
+        "matches1": torch.randint(-1, 50, (n_pairs, 7), generator=g),
+        "matching_scores0": torch.rand(n_pairs, 9, generator=g),
+        "matching_scores1": torch.rand(n_pairs, 7, generator=g),
+        "keypoints0": torch.rand(n_pairs, 9, 2, generator=g),
     }
-    lo, hi = shard_range(4, rank, world)
+    lo, hi = shard_range(n_pairs, rank, world)
     local = {k: v[lo:hi] for k, v in full.items()}
-    got = all_gather_matches(local, with_keypoints=True)
-    ok = all(torch.equal(got[k], full[k]) and got[k].dtype == full[k].dtype for k in full)
+    ok = True
+    for kw in ({}, {"num_pairs": n_pairs}):  # shard sizes exchanged by a tiny all-gather / derived from the global batch
+        stats = {}
+        got = all_gather_matches(local, with_keypoints=True, stats=stats, **kw)
+        ok = ok and all(torch.equal(got[k], full[k]) and got[k].dtype == full[k].dtype for k in full)
+        b_max = -(-n_pairs // world)
+        ok = ok and stats["bytes_sent"] == b_max * (9 + 7 + 9 + 7 + 18) * 4 and stats["bytes_received"] == world * stats["bytes_sent"]
+    if n_pairs % world:  # a wrong global batch is rejected before the collective, not after a hang
+        try:
+            all_gather_matches(local, num_pairs=n_pairs + world)
+            ok = False
+        except ValueError:
+            pass
     out[rank] = ok
     dist.destroy_process_group()
 
 
-def test_all_gather_matches_world2_gloo():
-    """N>1 path: each rank holds B/2 pairs; one packed all-gather reproduces the full-batch outputs."""
-    import sys
+def _spawn_gather(world, n_pairs):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     os.environ["PYTHONPATH"] = os.pathsep.join([root, os.path.join(root, "glue-factory_amd"), os.environ.get("PYTHONPATH", "")])
     mgr = mp.Manager()
     out = mgr.dict()
-    mp.spawn(_gather_worker, args=(2, _free_port(), out), nprocs=2, join=True)
-    assert out[0] and out[1]
+    mp.spawn(_gather_worker, args=(world, _free_port(), n_pairs, out), nprocs=world, join=True)
+    assert all(out[r] for r in range(world))
+
+
+def test_all_gather_matches_world2_gloo():
+    """N>1 path: each rank holds B/2 pairs; one packed all-gather reproduces the full-batch outputs."""
+    _spawn_gather(2, 4)
+
+
+def test_all_gather_matches_world3_uneven_gloo():
+    """B = 8 over 3 ranks = shards of 3/3/2 pairs: padded to the largest shard for the collective, padding dropped."""
+    _spawn_gather(3, 8)
+
+
+def test_composite_state_dict_round_trip():
+    """The reference's checkpoint path loads ONE state_dict into the composite (utils/experiments.py:90,
+    `model.load_state_dict(ckpt["model"], strict=False)`): keys are `extractor.*` / `matcher.*` with reference names."""
+    from gluefactory_amd.two_view_pipeline import TwoViewPipeline
+
+    conf = {"extractor": {"name": "gluefactory_nonfree.superpoint"}, "matcher": {"name": "matchers.lightglue"}}
+    W_sp, W_lg = O.make_sp_weights(0), O.make_lg_weights(3)
+    ckpt = {**{"extractor." + k: v for k, v in W_sp.items()}, **{"matcher." + k: v for k, v in W_lg.items()}}
+    p = TwoViewPipeline(conf)
+    assert not p.is_initialized()
+    assert [n for n, _ in p.named_parameters()] == ["extractor.weights_not_loaded", "matcher.weights_not_loaded"]
+    ret = p.load_state_dict(ckpt, strict=False)
+    assert not ret.missing_keys and not ret.unexpected_keys
+    assert p.is_initialized() and p.extractor.is_initialized() and p.matcher.is_initialized()
+    assert list(p.named_parameters()) == []  # the not-loaded markers are gone
+    sd = p.state_dict()
+    assert set(sd) == set(ckpt)
+    for k in ckpt:
+        assert torch.equal(sd[k], ckpt[k]), k
+    # strict round trip of its own state_dict, and of a legacy-named LightGlue checkpoint
+    q = TwoViewPipeline(conf)
+    q.load_state_dict(sd, strict=True)
+    assert all(torch.equal(q.state_dict()[k], sd[k]) for k in sd)
+    legacy = {k.replace("matcher.transformers.2.self_attn", "matcher.self_attn.2"): v for k, v in ckpt.items()}
+    r = TwoViewPipeline(conf)
+    r.load_state_dict(legacy, strict=True)
+    assert set(r.state_dict()) == set(ckpt)
+    # a checkpoint without the matcher leaves the composite un-initialised (eval/io.py:92-96 then raises)
+    u = TwoViewPipeline(conf)
+    u.load_state_dict({"extractor." + k: v for k, v in W_sp.items()}, strict=False)
+    assert u.extractor.is_initialized() and not u.matcher.is_initialized() and not u.is_initialized()
+    with pytest.raises(RuntimeError):
+        TwoViewPipeline(conf).load_state_dict({"extractor." + k: v for k, v in W_sp.items()}, strict=True)
+    # re-loading bumps the upload version so the engine re-tiles
+    v0 = p.matcher._weights_version
+    p.load_state_dict(ckpt)
+    assert p.matcher._weights_version == v0 + 1

@@ -1,0 +1,128 @@
+"""Tie-aware exact comparison of integer outputs (keypoint indices, match assignments) with the CPU oracle.
+
+north_star asks for bit-exact indices.  Floats of the HIP path and of the oracle differ by summation order
+(heat map: <= EPS_HEAT, asserted in the dense tests), so an index can legitimately differ only where the ORACLE's own
+decision was a near-tie.  These helpers accept a difference only when they can prove that from the oracle's numbers,
+and fail otherwise -- no percentage thresholds:
+
+  keypoints  every HIP keypoint is an NMS survivor of the oracle's score map; at every rank where the two lists hold a
+             different pixel, the oracle scores of the two pixels differ by < eps; the two sets are equal except for
+             swaps across rank K between pixels whose oracle scores are within eps of the oracle's K-th score.
+  matches    compared through keypoint COORDINATES (so a near-tie swap of two ranks is not a match error); a
+             differing assignment is accepted only if the oracle's own decision for the row had a margin < eps_la:
+             row arg-max margin, column arg-max margin (mutual check) or distance of the score to the filter threshold
+             (lightglue.py:287-303).
+
+Both return the counts they found so the tests can print them (DESIGN.md section 4b quotes them).
+"""
+import torch
+
+EPS_HEAT = 4e-6          # bound on |heat_hip - heat_oracle| asserted where the heat map is compared
+EPS_KP = 2 * EPS_HEAT    # two scores, each off by <= EPS_HEAT, can swap order only if they are closer than this
+
+
+def _pix(xy):
+    return (xy - 0.5).round().long()
+
+
+def check_keypoints(got_xy, ref_xy, ref_scores, nms_map, eps=EPS_KP, threshold=0.0, k_max=None):
+    """got_xy / ref_xy: (n,2) (x,y)+0.5 rows (valid rows only); ref_scores: (n,) oracle scores in oracle order;
+    nms_map: (H,W) the oracle's score map after NMS and border removal (superpoint.py:240-254).
+    Returns dict(n, rank_diffs, boundary_swaps, max_gap, perm) with perm[i] = oracle rank of HIP keypoint i (-1: not in the oracle's set)."""
+    assert got_xy.shape == ref_xy.shape, f"keypoint counts differ: {tuple(got_xy.shape)} vs {tuple(ref_xy.shape)}"
+    n = len(ref_xy)
+    gp, rp = _pix(got_xy), _pix(ref_xy)
+    H, W = nms_map.shape
+    assert bool(((gp[:, 0] >= 0) & (gp[:, 0] < W) & (gp[:, 1] >= 0) & (gp[:, 1] < H)).all()), "keypoint outside the image"
+    got_lin, ref_lin = gp[:, 1] * W + gp[:, 0], rp[:, 1] * W + rp[:, 0]
+    assert len(torch.unique(got_lin)) == n, "duplicate keypoints"
+    g_or = nms_map.reshape(-1)[got_lin]  # the oracle's score at the pixels the HIP path chose
+    assert bool((g_or > threshold).all()), "a HIP keypoint is not an NMS survivor / above threshold in the oracle's map (wrong pixel, not a tie)"
+    diff = got_lin != ref_lin
+    gap = (g_or - ref_scores).abs()
+    max_gap = float(gap[diff].max()) if bool(diff.any()) else 0.0
+    assert max_gap < eps, f"keypoint order differs at a rank where the oracle scores are {max_gap:.3e} apart (eps {eps:.1e}): not a near-tie"
+    # set equality, up to swaps across the rank-K boundary between near-ties of the K-th score
+    ref_pos = {int(v): i for i, v in enumerate(ref_lin.tolist())}
+    perm = torch.tensor([ref_pos.get(int(v), -1) for v in got_lin.tolist()])
+    extra = perm < 0
+    n_extra = int(extra.sum())
+    if n_extra:
+        assert k_max is not None and n == k_max, "sets differ although fewer than max_num_keypoints were detected"
+        kth = float(ref_scores.min())
+        assert bool(((g_or[extra] - kth).abs() < eps).all()), "a keypoint outside the oracle's set is not a near-tie of the oracle's K-th score"
+        got_set = set(got_lin.tolist())
+        missing = torch.tensor([v not in got_set for v in ref_lin.tolist()])
+        assert int(missing.sum()) == n_extra
+        assert bool(((ref_scores[missing] - kth).abs() < eps).all()), "an oracle keypoint missing from the HIP set is not a near-tie of the K-th score"
+    return {"n": n, "rank_diffs": int(diff.sum()), "boundary_swaps": n_extra, "max_gap": max_gap, "perm": perm}
+
+
+def match_margins(S, th):
+    """Per-entry decision margins of filter_matches (lightglue.py:287-303) on the oracle's log_assignment S (M+1,N+1):
+    how far entry (i,j) is from changing the row arg-max, the column arg-max, or its side of the score threshold."""
+    A = S[:-1, :-1]
+    M, N = A.shape
+    r2 = torch.topk(A, min(2, N), dim=1).values
+    c2 = torch.topk(A, min(2, M), dim=0).values
+    row_best, row_second = r2[:, :1], (r2[:, 1:2] if N > 1 else torch.full((M, 1), -float("inf")))
+    col_best, col_second = c2[:1], (c2[1:2] if M > 1 else torch.full((1, N), -float("inf")))
+    # margin to the best OTHER entry of the row / column
+    row_other = torch.where(A == row_best, row_second, row_best)
+    col_other = torch.where(A == col_best, col_second, col_best)
+    m_row = (A - row_other).abs()
+    m_col = (A - col_other).abs()
+    m_th = (A.exp() - th).abs()
+    return m_row, m_col, m_th
+
+
+def check_matches(got_m0, ref_m0, ref_S, th, eps_la, perm0=None, perm1=None, eps_th=None):
+    """got_m0: (M,) HIP matches0 (indices into the HIP keypoint order of image 1); ref_m0: (M,) oracle matches0;
+    ref_S: (M+1,N+1) oracle log_assignment; perm0/perm1: HIP rank -> oracle rank for image 0 / 1 (check_keypoints), None = identity.
+    Rows whose keypoint (or whose HIP match) is not in the oracle's set are skipped and counted.
+    Returns dict(rows, compared, differing, skipped, max_margin)."""
+    M, N = ref_S.shape[0] - 1, ref_S.shape[1] - 1
+    perm0 = torch.arange(M) if perm0 is None else perm0
+    perm1 = torch.arange(N) if perm1 is None else perm1
+    eps_th = eps_la if eps_th is None else eps_th
+    m_row, m_col, m_th = match_margins(ref_S, th)
+    compared = differing = skipped = 0
+    max_margin = 0.0
+    for i_hip in range(len(got_m0)):
+        i = int(perm0[i_hip])
+        j_hip = int(got_m0[i_hip])
+        if i < 0 or (j_hip >= 0 and int(perm1[j_hip]) < 0):
+            skipped += 1
+            continue
+        j_got = int(perm1[j_hip]) if j_hip >= 0 else -1
+        j_ref = int(ref_m0[i])
+        compared += 1
+        if j_got == j_ref:
+            continue
+        differing += 1
+        # every entry whose acceptance changed must have been a near-tie decision of the oracle
+        for j in {j_got, j_ref} - {-1}:
+            margin = min(float(m_row[i, j]), float(m_col[i, j]))
+            near = margin < eps_la or float(m_th[i, j]) < eps_th
+            max_margin = max(max_margin, margin if margin < eps_la else float(m_th[i, j]))
+            assert near, (f"match of oracle keypoint {i} differs (HIP -> {j_got}, oracle -> {j_ref}) although the oracle's decision margins for "
+                          f"({i},{j}) are row {float(m_row[i, j]):.3e} / column {float(m_col[i, j]):.3e} (eps {eps_la:.1e}) and "
+                          f"|score - th| {float(m_th[i, j]):.3e} (eps {eps_th:.1e}): not a near-tie")
+    return {"rows": len(got_m0), "compared": compared, "differing": differing, "skipped": skipped, "max_margin": max_margin}
+
+
+def to_oracle_order(got_la, perm0, perm1):
+    """HIP log_assignment (M+1,N+1) re-indexed to the oracle's keypoint order (perm from check_keypoints; sets must be equal)."""
+    assert bool((perm0 >= 0).all()) and bool((perm1 >= 0).all())
+    M, N = len(perm0), len(perm1)
+    r = torch.cat([perm0, torch.tensor([M])])
+    c = torch.cat([perm1, torch.tensor([N])])
+    out = torch.empty_like(got_la)
+    out[r[:, None], c[None, :]] = got_la
+    return out
+
+
+def la_eps(got_la, ref_la, floor=1e-5):
+    """Near-tie width for the assignment: twice the measured float error of log_assignment (two entries, each off by
+    that much, can swap).  The error itself is bounded by the float tolerance the same test asserts."""
+    return max(2.0 * float((got_la - ref_la).abs().max()), floor)
