@@ -675,7 +675,7 @@ int run_detect(mg_context* h, const mg_sp_conf* conf, const float* heat, int B, 
 // ================================================================================================
 extern "C" {
 
-int mg_abi_version(void) { return 5; }
+int mg_abi_version(void) { return MG_ABI_VERSION; }
 
 const char* mg_last_error(void) { return g_err.c_str(); }
 
@@ -960,7 +960,7 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
     if (f16) {
         XS = h->buf("lg.xs", T * 256);
         if (!XS) return fail(MG_ERR_HIP, "workspace allocation failed");
-        launch_to_sh8(X, XS, (long long)T * 256, s);
+        launch_to_sh8(X, XS, (long long)T * 256, 1.f, s);
     }
 
     auto ffn = [&](const LgBlock& blk) {
@@ -1141,7 +1141,7 @@ struct GnnRun {
     // copy, t0 / t1 = ping-pong activations (>= rows x 256), the last layer goes where `last` / last_act say
     void encoder(const LinLayer* enc, size_t rows, float* in32, float* in_sh8, float* t0, float* t1, float* last_act, const Opt& last) const {
         const float* a = in32;
-        if (f16) { launch_to_sh8(in32, in_sh8, (long long)rows * 32, s); a = in_sh8; }
+        if (f16) { launch_to_sh8(in32, in_sh8, (long long)rows * 32, 1.f, s); a = in_sh8; }
         Opt relu; relu.relu = 1;
         linear(enc[0], rows, a, 32, nullptr, 0, t0, 32, relu);
         linear(enc[1], rows, t0, 32, nullptr, 0, t1, 64, relu);
@@ -1431,8 +1431,8 @@ int mg_nn_forward(mg_handle h, const mg_nn_conf* conf, const float* desc0, const
         if (f16) {
             float* DS = h->buf("nn.desc", (T0 + T1) * D);
             if (!DS) return fail(MG_ERR_HIP, "workspace allocation failed");
-            launch_to_sh8(desc0, DS, (long long)T0 * D, s);
-            launch_to_sh8(desc1, DS + T0 * D, (long long)T1 * D, s);
+            launch_to_sh8(desc0, DS, (long long)T0 * D, 1.f, s);
+            launch_to_sh8(desc1, DS + T0 * D, (long long)T1 * D, 1.f, s);
             GemmF16Args g;
             g.A0 = DS; g.lda0 = D; g.ksplit = D;
             g.W = DS + T0 * D; g.w_rowmajor = 1; g.ldw = D;
@@ -1476,10 +1476,50 @@ int mg_test_linear(mg_handle h, const float* A, const float* W_host, const float
     std::vector<float> bias;
     if (bias_host) bias.assign(bias_host, bias_host + N);
     if (int rc = prep_linear_rows(h, rows, bias, K, &L)) return rc;
-    GemmArgs g = lin_args(L, A, K, M, C, N);
-    launch_gemm(g, static_cast<hipStream_t>(stream));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    if (h->precision == MG_PREC_F16X3) {
+        float* AS = h->buf("test.a", (size_t)M * K);
+        if (!AS) return fail(MG_ERR_HIP, "workspace allocation failed");
+        launch_to_sh8(A, AS, (long long)M * K, 1.f, s);
+        GemmF16Args g = lin_args_f16(L, AS, K, M);
+        g.C = C; g.ldc = N;
+        launch_gemm_f16x3(g, s);
+    } else {
+        GemmArgs g = lin_args(L, A, K, M, C, N);
+        launch_gemm(g, s);
+    }
     HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(static_cast<hipStream_t>(stream)));
+    HIPCHK(hipStreamSynchronize(s));
+    return 0;
+}
+
+int mg_test_attention(mg_handle h, const float* q, const float* k, const float* v, int B, int M, int N, int cross, float* out, void* stream) {
+    if (!h || !q || !k || !v || !out || B < 1 || M < 1 || N < 1) return fail(MG_ERR_ARG, "bad argument");
+    HIPCHK(hipSetDevice(h->device));
+    hipStream_t s = static_cast<hipStream_t>(stream);
+    const size_t T = (size_t)B * (M + N);
+    if (h->precision == MG_PREC_F16X3) {
+        float* QS = h->buf("test.q", T * 256);
+        float* KS = h->buf("test.k", T * 256);
+        float* VS = h->buf("test.v", T * 256);
+        float* OS = h->buf("test.o", T * 256);
+        if (!QS || !KS || !VS || !OS) return fail(MG_ERR_HIP, "workspace allocation failed");
+        launch_to_sh8(q, QS, (long long)T * 256, 1.4426950408889634f, s);  // the kernel exponentiates in base 2
+        launch_to_sh8(k, KS, (long long)T * 256, 1.f, s);
+        launch_to_sh8(v, VS, (long long)T * 256, 1.f, s);
+        AttnF16Args a;
+        a.q = QS; a.k = KS; a.v = VS; a.ld = 256; a.q_col = 0; a.k_col = 0; a.v_col = 0;
+        a.out = OS; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+        launch_attention_f16x3(a, s);
+        launch_from_sh8(OS, out, (long long)T * 256, s);
+    } else {
+        AttnArgs a;
+        a.q = q; a.k = k; a.v = v; a.ld = 256; a.q_col = 0; a.k_col = 0; a.v_col = 0;
+        a.out = out; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+        launch_attention(a, s);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s));
     return 0;
 }
 

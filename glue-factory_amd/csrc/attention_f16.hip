@@ -22,12 +22,21 @@ namespace {
 constexpr int KT = 32, AT = 512, QW = 64;  // keys per tile; 8 waves x 64 queries (two MFMA tiles) per workgroup
 constexpr float RESCALE_THR = 8.f;  // in log2 units
 
-// x (>= 0, fp16 range) -> packed (hi, lo) halves of a pair, hi rounded toward zero.
+// The probabilities are kept as P' = 2^P_SHIFT * exp2(s - m_run): with the deferred rescale s - m_run <= RESCALE_THR, so
+// P' <= 2^15 stays inside fp16 range, and the fp16-subnormal zone of the halves (< 2^-14) starts at P < 2^-21 instead of
+// 2^-14: what a 2048-key row can lose to it is < 2048 * 2^-24-7 = 1e-6 of the row sum (it was 1.2e-4, the whole tolerance,
+// for an adversarial row before the shift).  l_run and the accumulators carry the same factor; it cancels in O / l.
+constexpr float P_SHIFT = 7.f;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+
+// x (>= 0, fp16 range) -> packed (hi, lo) halves of a pair: hi = x truncated to 11 significant bits (a mask: exact in
+// fp16 above the subnormal zone), lo = fp16(x - hi) rounded to nearest (v_cvt_pk_f16_f32) -> 22 bits, unbiased.
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
     const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xFFFFE000u);
     const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xFFFFE000u);
     hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-    lo = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0 - h0, x1 - h1));
+    const f16x2 l = {(_Float16)(x0 - h0), (_Float16)(x1 - h1)};
+    lo = __builtin_bit_cast(unsigned, l);
 }
 
 __global__ __launch_bounds__(AT, 2) void attention_f16x3_kernel(const AttnF16Args p) {
@@ -137,9 +146,10 @@ __global__ __launch_bounds__(AT, 2) void attention_f16x3_kernel(const AttnF16Arg
                 m_run[qt] = m_new;
             }
             float ps = 0.f;
+            const float m_off = m_run[qt] - P_SHIFT;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                s[qt][r] = __builtin_amdgcn_exp2f(s[qt][r] - m_run[qt]);
+                s[qt][r] = __builtin_amdgcn_exp2f(s[qt][r] - m_off);
                 ps += s[qt][r];
             }
             l_run[qt] += ps;

@@ -308,16 +308,26 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
 }
 
 // fp32 rows -> SH8 rows (entry of the LightGlue residual stream; C % 8 == 0).  One thread per group of 8.
-__global__ __launch_bounds__(256) void to_sh8_kernel(const float* __restrict__ in, void* __restrict__ out, long long groups) {
+__global__ __launch_bounds__(256) void to_sh8_kernel(const float* __restrict__ in, void* __restrict__ out, long long groups, float scale) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
     if (g >= groups) return;
-    const f32x4 a = *reinterpret_cast<const f32x4*>(in + g * 8), b = *reinterpret_cast<const f32x4*>(in + g * 8 + 4);
+    const f32x4 a = *reinterpret_cast<const f32x4*>(in + g * 8) * scale, b = *reinterpret_cast<const f32x4*>(in + g * 8 + 4) * scale;
     const f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
     f16x8 hi, lo;
     split8(v, hi, lo);
     f16x8* o = reinterpret_cast<f16x8*>(out) + g * 2;
     o[0] = hi;
     o[1] = lo;
+}
+
+// SH8 rows -> fp32 rows (test entries only)
+__global__ __launch_bounds__(256) void from_sh8_kernel(const void* __restrict__ in, float* __restrict__ out, long long groups) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const f16x8* i = reinterpret_cast<const f16x8*>(in) + g * 2;
+    const f16x8 hi = i[0], lo = i[1];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[g * 8 + j] = (float)hi[j] + (float)lo[j];
 }
 
 }  // namespace
@@ -338,7 +348,12 @@ void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
     }
 }
 
-void launch_to_sh8(const float* in, void* out, long long elems, hipStream_t s) {
+void launch_to_sh8(const float* in, void* out, long long elems, float scale, hipStream_t s) {
     const long long groups = elems / 8;
-    hipLaunchKernelGGL(to_sh8_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, in, out, groups);
+    hipLaunchKernelGGL(to_sh8_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, in, out, groups, scale);
+}
+
+void launch_from_sh8(const void* in, float* out, long long elems, hipStream_t s) {
+    const long long groups = elems / 8;
+    hipLaunchKernelGGL(from_sh8_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, in, out, groups);
 }

@@ -111,7 +111,8 @@ struct GemmF16Args {
     int debug = 0;  // timing experiments: 1 = skip the stores, 2 = skip the main loop
 };
 void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s);
-void launch_to_sh8(const float* in, void* out, long long elems, hipStream_t s);
+void launch_to_sh8(const float* in, void* out, long long elems, float scale, hipStream_t s);  // SH8(in * scale)
+void launch_from_sh8(const void* in, float* out, long long elems, hipStream_t s);          // hi + lo back to fp32
 
 // ---- sp_post.hip ---------------------------------------------------------------------------------
 void launch_softmax_d2s(const float* logits, int ld, int B, int hc, int wc, float* heat, hipStream_t s);

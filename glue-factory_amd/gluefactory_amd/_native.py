@@ -21,7 +21,7 @@ MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN = 0, 1, 2
 EXPORTS = [
     "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_precision", "mg_set_weight", "mg_weights_ready",
     "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_sg_forward", "mg_gs_forward", "mg_nn_forward", "mg_debug_request", "mg_debug_read",
-    "mg_profile_enable", "mg_profile_read", "mg_test_linear",
+    "mg_profile_enable", "mg_profile_read", "mg_test_linear", "mg_test_attention",
 ]
 
 
@@ -86,6 +86,7 @@ def lib():
     L.mg_profile_enable.argtypes = [c_void_p, c_int]
     L.mg_profile_read.argtypes = [c_void_p, c_void_p, POINTER(c_float), c_int]
     L.mg_test_linear.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p]
+    L.mg_test_attention.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     _lib = L
     return L
 
@@ -323,3 +324,13 @@ class Engine:
         _check(lib().mg_test_linear(self._h, _ptr(A), c_void_p(Wc.data_ptr()), None if bc is None else c_void_p(bc.data_ptr()), M, N, K,
                                     _ptr(C), _stream(self.device)))
         return C
+
+    def test_attention(self, q, k, v, B, M, N, cross=False):
+        """softmax(q k^T) v per head on (B*(M+N), 256) token rows (image-0 rows first), in the engine's precision mode."""
+        q, k, v = (_f32(t, self.device) for t in (q, k, v))
+        T = B * (M + N)
+        if q.shape != (T, 256) or k.shape != (T, 256) or v.shape != (T, 256):
+            raise RuntimeError("q, k, v must be (B*(M+N), 256)")
+        out = torch.empty(T, 256, device=self.device)
+        _check(lib().mg_test_attention(self._h, _ptr(q), _ptr(k), _ptr(v), B, M, N, 1 if cross else 0, _ptr(out), _stream(self.device)))
+        return out

@@ -64,7 +64,8 @@ int mg_create(int device, mg_handle* out);
 int mg_destroy(mg_handle h);
 const char* mg_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
-int mg_abi_version(void);
+#define MG_ABI_VERSION 6 /* bumped whenever an entry point or a conf struct changes */
+int mg_abi_version(void);   /* == MG_ABI_VERSION of the header the library was built from */
 
 /* -- arithmetic ------------------------------------------------------------------------------
  * MG_PREC_F32   : fp32-input MFMA everywhere (v_mfma_f32_32x32x2_f32), bit-for-bit an fp32 FMA chain.
@@ -189,9 +190,18 @@ int mg_debug_read(mg_handle h, const char* tap, float* dst, size_t capacity, siz
 int mg_profile_enable(mg_handle h, int on);
 int mg_profile_read(mg_handle h, char (*names)[48], float* ms, int cap);
 
-/* Stand-alone GEMM self-test entry: C[M,N] = A[M,K] * W[N,K]^T + bias (fp32-in MFMA core).     */
+/* Stand-alone self-test entries of the two matrix cores, in the arithmetic mode set by mg_set_precision()
+ * (f32: fp32-input MFMA kernels; f16x3: the split-fp16 kernels the benchmark runs), for unit tests over wide
+ * operand ranges against fp64.
+ * mg_test_linear:    C[M,N] = A[M,K] * W[N,K]^T + bias; A, C device fp32, W / bias host fp32; K % 32 == 0.
+ * mg_test_attention: out = softmax(q k^T) v per head (4 heads x 64, the caller has applied any logit scale to q):
+ *                    q, k, v, out device fp32 (tokens, 256), rows = image-0 tokens (B*M) then image-1 tokens (B*N);
+ *                    cross = 0: every sequence attends to itself, 1: to the other image of its pair
+ *                    (lightglue.py:105-115, :200-210).                                                         */
 int mg_test_linear(mg_handle h, const float* A, const float* W_host, const float* bias_host, int M, int N,
                    int K, float* C, void* stream);
+int mg_test_attention(mg_handle h, const float* q, const float* k, const float* v, int B, int M, int N, int cross,
+                      float* out, void* stream);
 
 #ifdef __cplusplus
 }

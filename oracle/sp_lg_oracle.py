@@ -411,17 +411,22 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
 # --------------------------------------------------------------------------
 # Two-view composite
 # --------------------------------------------------------------------------
-def two_view_forward(data, W_sp, W_lg, sp_conf, lg_conf):
-    """two_view_pipeline.py:62-90 -- extractor per view, keys suffixed 0/1, then the matcher."""
-    pred = {}
+def two_view_forward(data, W_sp, W_lg, sp_conf, lg_conf, with_maps=False):
+    """two_view_pipeline.py:62-90 -- extractor per view, keys suffixed 0/1, then the matcher.
+    `with_maps` also returns the score maps behind the keypoint decisions (`_nms_scores0/1`, `_heatmap0/1`) for
+    the tie-aware index checks of the tests; they are not part of the reference's pred dict."""
+    pred, maps = {}, {}
     for i in ("0", "1"):
         p = superpoint_forward(data["view" + i], W_sp, **sp_conf)
         for k in ("keypoints", "keypoint_scores", "descriptors"):
             pred[k + i] = p[k]
         if sp_conf.get("variant") == "open":
             pred["heatmap" + i] = p["heatmap"]
+        maps["_nms_scores" + i], maps["_heatmap" + i] = p["nms_scores"], p["heatmap"]
     lg = lightglue_forward({**data, **pred}, W_lg, **lg_conf)
     pred.update({k: v for k, v in lg.items() if not k.startswith("_")})
+    if with_maps:
+        pred.update(maps)
     return pred
 
 

@@ -31,7 +31,8 @@ def test_library_exports_every_declared_symbol(libpath):
     lib = ctypes.CDLL(libpath)
     for sym in declared_symbols():
         assert hasattr(lib, sym), sym
-    assert lib.mg_abi_version() == 5
+    want = int(re.search(r"#define\s+MG_ABI_VERSION\s+(\d+)", open(os.path.join(ROOT, "include", "matchglue.h")).read()).group(1))
+    assert lib.mg_abi_version() == want
 
 
 def test_struct_layouts_match_header():

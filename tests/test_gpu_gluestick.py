@@ -87,10 +87,17 @@ def test_gluestick_vs_oracle_large(dev, precision):
         err = (p[k].cpu() - ref[k]).abs().max().item()
         print(f"[{precision}] max|{k} err| {err:.2e}")
         torch.testing.assert_close(p[k].cpu(), ref[k], rtol=2e-5, atol=5e-4)
-    for k in GS_INT:
-        agree = (p[k].cpu() == ref[k]).float().mean().item()
-        print(f"[{precision}] {k}: agreement {agree:.5f}, matched {(ref[k] > -1).float().mean().item():.3f}")
-        assert agree > 0.995
+    # assignments identical except at proven near-ties of the oracle's own decision (tests/tie_aware.py); no percentage
+    import tie_aware as TA
+
+    for pre in ("", "line_"):
+        for b in range(B):
+            S = ref[pre + "log_assignment"][b]
+            eps = TA.la_eps(p[pre + "log_assignment"][b].cpu(), S)
+            r0 = TA.check_matches(p[pre + "matches0"][b].cpu(), ref[pre + "matches0"][b], S, 0.2, eps)
+            r1 = TA.check_matches(p[pre + "matches1"][b].cpu(), ref[pre + "matches1"][b], S.t(), 0.2, eps)
+            print(f"[{precision}] {pre}matches pair {b}: {r0['differing']}/{r0['compared']} and {r1['differing']}/{r1['compared']} differ (near-ties, eps {eps:.1e}); "
+                  f"matched {(ref[pre + 'matches0'][b] > -1).float().mean().item():.3f}")
     # oracle-independent: mutual consistency of both assignments, rows of exp(S) are sub-stochastic
     for pre, m in (("", M), ("line_", n0)):
         m0, m1 = p[pre + "matches0"], p[pre + "matches1"]

@@ -2,11 +2,14 @@
 
 Bar (BASELINE.json north_star): integer outputs (keypoint indices, match assignments) exact,
 floats within 1e-4.  Stage-wise tests feed each kernel the *reference's* upstream tensor so that
-integer outputs must match exactly; end-to-end tests additionally report rank flips.
+integer outputs must match exactly; end-to-end tests compare indices with the tie-aware rule of
+tests/tie_aware.py: a difference is accepted only where the oracle's own decision was a near-tie
+(proved from the oracle's score map / log_assignment), never by a percentage.
 """
 import pytest
 import torch
 
+import tie_aware as TA
 from oracle import sp_lg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -195,16 +198,15 @@ def test_superpoint_dense_vs_oracle_vga(dev, variant, precision):
     ref = O.superpoint_forward({"image": img}, W, variant="open" if variant == "open" else "magicleap", **{k: v for k, v in conf.items() if k != "force_num_keypoints"})
     eng = m.engine(dev)
     kp, sc, ds, nv, heat, dense = eng.sp_forward(m._native_conf(), img.to(dev), None, want_heatmap=True, want_dense=True)
-    torch.testing.assert_close(heat.cpu(), ref["heatmap"], rtol=0, atol=ATOL)
+    # the heat map is held to EPS_HEAT: that bound is what makes EPS_KP = 2 EPS_HEAT the near-tie width for keypoint ranks
+    torch.testing.assert_close(heat.cpu(), ref["heatmap"], rtol=0, atol=TA.EPS_HEAT)
     torch.testing.assert_close(dense.cpu(), ref["dense_descriptors"], rtol=0, atol=ATOL)
+    print(f"[{variant}/{precision}] max|heat err| {(heat.cpu() - ref['heatmap']).abs().max().item():.2e} max|dense err| {(dense.cpu() - ref['dense_descriptors']).abs().max().item():.2e}")
     for b in range(2):
-        a = set(map(tuple, kp[b].cpu().tolist()))
-        c = set(map(tuple, ref["keypoints_list"][b].tolist()))
-        same_pos = (kp[b].cpu() == ref["keypoints_list"][b]).all(-1).float().mean().item()
-        print(f"[{variant}/{precision}] max|heat err| {(heat.cpu() - ref['heatmap']).abs().max().item():.2e} max|dense err| {(dense.cpu() - ref['dense_descriptors']).abs().max().item():.2e}")
-        print(f"[{variant}/{precision}] image {b}: keypoint set overlap {len(a & c)}/1024, same rank {same_pos:.4f}")
-        assert len(a & c) >= 1014  # <= 1 % membership flips at rank K from fp32 summation order
-        assert same_pos > 0.97
+        r = TA.check_keypoints(kp[b].cpu(), ref["keypoints_list"][b], ref["keypoint_scores_list"][b], ref["nms_scores"][b], k_max=1024)
+        print(f"[{variant}/{precision}] image {b}: {r['rank_diffs']} rank differences (max oracle-score gap {r['max_gap']:.2e} < {TA.EPS_KP:.0e}), "
+              f"{r['boundary_swaps']} swaps across rank K")
+        torch.testing.assert_close(sc[b].cpu()[r["perm"] >= 0], ref["keypoint_scores_list"][b][r["perm"][r["perm"] >= 0]], rtol=0, atol=TA.EPS_HEAT)
     # stage-wise: detector fed the oracle's heatmap must be exact
     kp2, sc2, nv2, _ = eng.sp_detect(m._native_conf(), ref["heatmap"])
     for b in range(2):
@@ -283,12 +285,18 @@ def test_lightglue_vs_oracle_fullsize(dev, B, M, N, precision):
     # stress weights (final_proj = 8*I) push |sim| past 1e2, where one fp32 ulp is 8e-6..1.5e-5 and the
     # similarity enters every entry twice (row + column log-softmax): allow a few ulps of |sim|
     torch.testing.assert_close(p["log_assignment"].cpu(), ref["log_assignment"], rtol=2e-5, atol=5e-4)
-    agree = (p["matches0"].cpu() == ref["matches0"]).float().mean().item()
     print(f"[{precision}] max|desc err| {(p['ref_descriptors0'][:, 0].cpu() - ref['ref_descriptors0'][:, 0]).abs().max().item():.2e} "
           f"max|log_assignment err| {(p['log_assignment'].cpu() - ref['log_assignment']).abs().max().item():.2e}")
-    print(f"B{B} M{M} N{N}: matches0 agreement {agree:.5f}, matched {(ref['matches0'] > -1).float().mean().item():.3f}")
-    assert agree > 0.999
-    torch.testing.assert_close(p["matching_scores0"].cpu(), ref["matching_scores0"], rtol=0, atol=2e-4)
+    # assignments: identical, except where the oracle's own row / column / threshold decision is closer than twice the measured
+    # float error of log_assignment (tests/tie_aware.py) -- anything else fails
+    for b in range(B):
+        eps = TA.la_eps(p["log_assignment"][b].cpu(), ref["log_assignment"][b])
+        r0 = TA.check_matches(p["matches0"][b].cpu(), ref["matches0"][b], ref["log_assignment"][b], 0.1, eps)
+        r1 = TA.check_matches(p["matches1"][b].cpu(), ref["matches1"][b], ref["log_assignment"][b].t(), 0.1, eps)
+        print(f"[{precision}] B{B} M{M} N{N} pair {b}: matches0 {r0['differing']}/{r0['compared']} differ, matches1 {r1['differing']}/{r1['compared']} differ "
+              f"(all near-ties, eps {eps:.1e}); matched {(ref['matches0'][b] > -1).float().mean().item():.3f}")
+    same = p["matches0"].cpu() == ref["matches0"]
+    torch.testing.assert_close(p["matching_scores0"].cpu()[same], ref["matching_scores0"][same], rtol=0, atol=2e-4)
     # properties independent of the oracle: mutual consistency of the assignment (lightglue.py:293-301)
     m0, m1 = p["matches0"], p["matches1"]
     idx = torch.arange(M, device=dev)[None].expand(B, -1)
@@ -316,25 +324,28 @@ def test_two_view_boat_golden(dev, golden, variant, precision):
     im0 = (g["gray0"].float()[None, None] / 255.0).to(dev)
     im1 = (g["gray1"].float()[None, None] / 255.0).to(dev)
     size = torch.tensor([[im0.shape[-1], im0.shape[-2]]], device=dev).float()
-    p = pipe({"view0": {"image": im0, "image_size": size}, "view1": {"image": im1, "image_size": size}})
+    W_sp, W_lg = O.make_sp_weights(0, "open" if variant == "open" else "magicleap"), O.make_lg_weights(7, structured=True, final_gain=8.0, match_bias=2.0)
+    spc = dict(variant="open" if variant == "open" else "magicleap", nms_radius=3, detection_threshold=0.0, max_num_keypoints=512)
+    cpu = lambda d: {k: v.cpu() for k, v in d.items()}
+
+    data = {"view0": {"image": im0, "image_size": size}, "view1": {"image": im1, "image_size": size}}
+    p = pipe(data)
     assert sorted(p.keys()) == list(g[variant + ".keys"])
+    # the oracle reproduces the golden (= the reference run on this pair) bit for bit; its score maps then decide what is a near-tie
+    ref = O.two_view_forward({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in data.items()}, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
     for k in ("keypoints0", "keypoints1"):
-        same = (p[k].cpu() == g[f"{variant}.{k}"]).all(-1).float().mean().item()
-        print(f"[{variant}] {k}: identical rows {same:.4f}")
-        assert same > 0.98
-    torch.testing.assert_close(p["keypoint_scores0"].cpu().sort().values, g[variant + ".keypoint_scores0"].sort().values, rtol=0, atol=ATOL)
+        assert torch.equal(ref[k], g[f"{variant}.{k}"])
+    TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat {variant}/{precision}")
     # shifted self-pair: genuine correspondences
     a = im0[:, :, 0:640, 0:800].contiguous()
     b = im0[:, :, 16:656, 24:824].contiguous()
     size = torch.tensor([[800.0, 640.0]], device=dev)
-    p = pipe({"view0": {"image": a, "image_size": size}, "view1": {"image": b, "image_size": size}})
-    kp_same = (p["keypoints0"].cpu() == g[variant + ".shift.keypoints0"]).all(-1).float().mean().item()
-    m_same = (p["matches0"].cpu() == g[variant + ".shift.matches0"]).float().mean().item()
-    print(f"[{variant}] shifted pair: keypoints identical {kp_same:.4f}, matches identical {m_same:.4f}, matched {(p['matches0'] > -1).sum().item()}")
-    assert kp_same > 0.98 and m_same > 0.97
-    if kp_same == 1.0:
-        assert m_same == 1.0
-        torch.testing.assert_close(p["matching_scores0"].cpu(), g[variant + ".shift.matching_scores0"], rtol=0, atol=1e-3)
+    data = {"view0": {"image": a, "image_size": size}, "view1": {"image": b, "image_size": size}}
+    p = pipe(data)
+    ref = O.two_view_forward({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in data.items()}, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
+    assert torch.equal(ref["keypoints0"], g[variant + ".shift.keypoints0"]) and torch.equal(ref["matches0"], g[variant + ".shift.matches0"])
+    r = TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat-shift {variant}/{precision}")
+    assert (ref["matches0"] > -1).sum() > 100 and r["m0"]["compared"] > 500
 
 
 def test_two_view_config3_padded_vs_oracle(dev):
@@ -353,29 +364,20 @@ def test_two_view_config3_padded_vs_oracle(dev):
     W_sp, W_lg = O.make_sp_weights(0), O.make_lg_weights(7, structured=True, final_gain=8.0, match_bias=2.0)
     spc = dict(nms_radius=3, detection_threshold=0.0, max_num_keypoints=2048)
     data = {"view0": {"image": im0, "image_size": size}, "view1": {"image": im1, "image_size": size}}
-    ref = O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1))
+    ref = O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
     pipe = TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint", **spc},
                             "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1}}).eval()
     pipe.extractor.load_state_dict(W_sp)
     pipe.matcher.load_state_dict(W_lg)
     to = lambda x: {k: (to(v) if isinstance(v, dict) else v.to(dev)) for k, v in x.items()}
-    p = pipe(to(data))
+    p = {k: v.cpu() for k, v in pipe(to(data)).items()}
     assert p["keypoints0"].shape == (1, 2048, 2) and p["matches0"].shape == (1, 2048)
     # nothing is detected in the padding or within 4 px of the valid region's border
     for k in ("keypoints0", "keypoints1"):
-        kp = p[k][0].cpu() - 0.5
+        kp = p[k][0] - 0.5
         assert kp[:, 1].max() < 768 - 4 and kp[:, 0].max() < 1024 - 4 and kp.min() >= 4
-        a, c = set(map(tuple, p[k][0].cpu().tolist())), set(map(tuple, ref[k][0].tolist()))
-        same = (p[k].cpu() == ref[k]).all(-1).float().mean().item()
-        print(f"{k}: set overlap {len(a & c)}/2048, same rank {same:.4f}")
-        assert len(a & c) >= 2028 and same > 0.97
-    kp_same = all((p[k].cpu() == ref[k]).all() for k in ("keypoints0", "keypoints1"))
-    m_same = (p["matches0"].cpu() == ref["matches0"]).float().mean().item()
-    print(f"matches identical {m_same:.4f}, matched {(ref['matches0'] > -1).sum().item()} (keypoints identical: {kp_same})")
     assert (ref["matches0"] > -1).sum() > 500
-    assert m_same > 0.97
-    if kp_same:
-        assert m_same == 1.0
+    TA.check_two_view(p, ref, 0, 2048, 0.1, tag="config3 padded")
 
 
 def test_fused_views_equal_separate_calls(dev):

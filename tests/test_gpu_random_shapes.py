@@ -1,9 +1,10 @@
 """Seeded random shapes through the whole native path against the oracle: odd image sizes (not multiples of the conv
 tiles), batch sizes 1-3, ragged keypoint counts, both SuperPoint layouts.  Floats within the north-star tolerance;
-keypoint sets / matches compared with the same near-tie allowance as the fixed-size tests."""
+keypoint indices / matches compared with the tie-aware exact rule of tests/tie_aware.py (no percentage thresholds)."""
 import pytest
 import torch
 
+import tie_aware as TA
 from oracle import sp_lg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -43,23 +44,34 @@ def test_two_view_random_shapes(dev, seed):
                             "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1}}).eval()
     pipe.extractor.load_state_dict(W_sp)
     pipe.matcher.load_state_dict(W_lg)
-    p = pipe(_to(data, dev))
+    p = {k: v.cpu() for k, v in pipe(_to(data, dev)).items()}
+    solo = TwoViewPipeline({"extractor": {"name": name, **{k: v for k, v in spc.items() if k != "variant"}}, "fuse_views": False,
+                            "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1}}).eval()
+    solo.extractor.load_state_dict(W_sp)
+    solo.matcher.load_state_dict(W_lg)
     # oracle per pair (the reference batches only equal keypoint counts)
-    kp_same, m_same, n = 0.0, 0.0, 0
+    n_full = 0
     for b in range(B):
         one = {"view0": {"image": img[b:b + 1], "image_size": size[:1]}, "view1": {"image": img[B + b:B + b + 1], "image_size": size[:1]}}
-        ref = O.two_view_forward(one, W_sp, W_lg, spc, dict(filter_threshold=0.1))
+        ref = O.two_view_forward(one, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
+        counts = [ref["keypoints" + i].shape[1] for i in ("0", "1")]
+        tag = f"seed {seed} B{B} {W}x{H} C{C} K{K} r{spc['nms_radius']} {variant}"
+        if counts == [K, K]:
+            TA.check_two_view(p, ref, b, K, 0.1, tag=tag)
+            n_full += 1
+        else:
+            # fewer than K detections: the batched rows are zero-padded (a documented difference from the reference's random
+            # padding, superpoint.py:304-317) and the matcher sees the padding, so the batch is checked up to the extractor ...
+            for i in ("0", "1"):
+                n = counts[int(i)]
+                r = TA.check_keypoints(p["keypoints" + i][b, :n], ref["keypoints" + i][0], ref["keypoint_scores" + i][0], ref["_nms_scores" + i][0], k_max=K)
+                assert bool((p["keypoint_scores" + i][b, n:] == 0).all()) and bool((p["keypoints" + i][b, n:] == 0).all())
+                ok = r["perm"] >= 0
+                torch.testing.assert_close(p["descriptors" + i][b, :n][ok], ref["descriptors" + i][0][r["perm"][ok]], rtol=0, atol=ATOL)
+            # ... and the pair alone (rows trimmed to the detected count, as the reference returns them) end to end
+            q = {k: v.cpu() for k, v in solo(_to(one, dev)).items()}
+            TA.check_two_view(q, ref, 0, K, 0.1, tag=tag + " (alone)")
         for i in ("0", "1"):
-            nk = ref["keypoints" + i].shape[1]
-            got = p["keypoints" + i][b, :nk].cpu()
-            a, c = set(map(tuple, got.tolist())), set(map(tuple, ref["keypoints" + i][0].tolist()))
-            assert len(a & c) >= nk - max(2, nk // 50), (seed, b, i, len(a & c), nk, H, W, K, variant)
-            kp_same += float((got == ref["keypoints" + i][0]).all(-1).float().mean())
-            n += 1
-        nk0 = ref["matches0"].shape[1]
-        if all((p["keypoints" + i][b, : ref["keypoints" + i].shape[1]].cpu() == ref["keypoints" + i][0]).all() for i in ("0", "1")):
-            assert torch.equal(p["matches0"][b, :nk0].cpu(), ref["matches0"][0]), (seed, b, H, W, K, variant)
-            torch.testing.assert_close(p["matching_scores0"][b, :nk0].cpu(), ref["matching_scores0"][0], rtol=0, atol=2e-4)
-            m_same += 1
-    print(f"seed {seed}: B{B} {W}x{H} C{C} K{K} r{spc['nms_radius']} {variant}: same-rank keypoints {kp_same / n:.4f}, pairs with identical keypoints {int(m_same)}/{B}")
-    assert kp_same / n > 0.95
+            n = counts[int(i)]
+            torch.testing.assert_close(p["keypoint_scores" + i][b, :n].sort().values, ref["keypoint_scores" + i][0].sort().values, rtol=0, atol=ATOL)
+    print(f"seed {seed}: B{B} {W}x{H} C{C} K{K} r{spc['nms_radius']} {variant}: {n_full}/{B} pairs with K keypoints in both images")

@@ -126,3 +126,58 @@ def la_eps(got_la, ref_la, floor=1e-5):
     """Near-tie width for the assignment: twice the measured float error of log_assignment (two entries, each off by
     that much, can swap).  The error itself is bounded by the float tolerance the same test asserts."""
     return max(2.0 * float((got_la - ref_la).abs().max()), floor)
+
+
+def check_two_view(p, ref, b, k_max, th, tag="", la_floor=1e-5, score_atol=2e-4):
+    """One pair of a two-view result against the oracle's result for that pair (O.two_view_forward(..., with_maps=True), B = 1).
+
+    p: HIP pred dict (CPU tensors, batch index b is compared); ref: oracle pred for the single pair.
+    Keypoints of both images under the tie-aware rule; matches0 / matches1 through keypoint coordinates under the
+    near-tie rule with eps = 2 x the measured log_assignment error; matching scores within `score_atol` wherever the
+    assignment agrees.  Returns the counts (and prints them)."""
+    out = {}
+    perms = []
+    for i in ("0", "1"):
+        n = ref["keypoints" + i].shape[1]
+        if p["keypoints" + i].shape[1] > n:  # fixed-K rows: everything past the detected count is zero padding
+            assert bool((p["keypoint_scores" + i][b, n:] == 0).all()), "rows past the oracle's keypoint count are not padding"
+        r = check_keypoints(p["keypoints" + i][b, :n], ref["keypoints" + i][0], ref["keypoint_scores" + i][0], ref["_nms_scores" + i][0],
+                            k_max=k_max)
+        perms.append(r["perm"])
+        out["kp" + i] = {k: v for k, v in r.items() if k != "perm"}
+    M, N = len(perms[0]), len(perms[1])
+    sets_equal = bool((perms[0] >= 0).all()) and bool((perms[1] >= 0).all())
+    S = ref["log_assignment"][0]
+    eps = la_floor
+    if sets_equal and "log_assignment" in p:
+        got_la = to_oracle_order(p["log_assignment"][b][: M + 1, : N + 1] if p["log_assignment"].shape[1] == M + 1 else
+                                 _crop_la(p["log_assignment"][b], M, N), perms[0], perms[1])
+        out["la_err"] = float((got_la - S).abs().max())
+        eps = max(2 * out["la_err"], la_floor)
+    out["eps_la"] = eps
+    out["m0"] = check_matches(p["matches0"][b, :M], ref["matches0"][0], S, th, eps, perms[0], perms[1])
+    out["m1"] = check_matches(p["matches1"][b, :N], ref["matches1"][0], S.t(), th, eps, perms[1], perms[0])
+    # scores where both sides made the same assignment
+    inv1 = {int(v): j for j, v in enumerate(perms[1].tolist()) if v >= 0}
+    worst = 0.0
+    for i_h in range(M):
+        i = int(perms[0][i_h])
+        if i < 0:
+            continue
+        j_h = int(p["matches0"][b, i_h])
+        j_ref = int(ref["matches0"][0, i])
+        if (j_h < 0) != (j_ref < 0) or (j_h >= 0 and int(perms[1][j_h]) != j_ref):
+            continue
+        worst = max(worst, abs(float(p["matching_scores0"][b, i_h]) - float(ref["matching_scores0"][0, i])))
+    assert worst < score_atol, f"matching_scores0 differ by {worst:.2e} where the assignment agrees"
+    out["score_err"] = worst
+    print(f"[tie-aware{' ' + tag if tag else ''}] pair {b}: keypoints0 {out['kp0']}, keypoints1 {out['kp1']}; "
+          f"matches0 {out['m0']}, matches1 {out['m1']} (eps_la {eps:.2e}, la err {out.get('la_err', float('nan')):.2e}, score err {worst:.2e})")
+    return out
+
+
+def _crop_la(la, M, N):
+    """(Mk+1, Nk+1) log_assignment of fixed-K rows -> the (M+1, N+1) block of the valid rows plus the dustbins."""
+    r = torch.cat([torch.arange(M), torch.tensor([la.shape[0] - 1])])
+    c = torch.cat([torch.arange(N), torch.tensor([la.shape[1] - 1])])
+    return la[r][:, c]
