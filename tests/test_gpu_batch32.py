@@ -44,7 +44,7 @@ def boat_pairs(B, H, W, Hv, seed):
 def run_case(dev, precision, B, H, W, Hv, K, oracle_pairs):
     from gluefactory_amd.two_view_pipeline import TwoViewPipeline
 
-    W_sp, W_lg = O.make_sp_weights(0), O.make_lg_weights(7, structured=True, final_gain=8.0, match_bias=2.0)
+    W_sp, W_lg = O.make_sp_weights(0), O.make_lg_weights(7, structured=True, final_gain=3.0, match_bias=2.0)
     spc = dict(nms_radius=3, detection_threshold=0.0, max_num_keypoints=K)
     pipe = TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint", "remove_borders": 4, "force_num_keypoints": True, "precision": precision, **spc},
                             "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1, "precision": precision}}).eval()
@@ -65,13 +65,12 @@ def run_case(dev, precision, B, H, W, Hv, K, oracle_pairs):
     for i in oracle_pairs:
         data = {"view0": {"image": im0[i:i + 1], "image_size": size[:1]}, "view1": {"image": im1[i:i + 1], "image_size": size[:1]}}
         ref = O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
-        r = TA.check_two_view(p, ref, i, K, 0.1, tag=f"{W}x{H} K{K} B{B} {precision}")
+        r = TA.check_two_view(p, ref, i, K, 0.1, tag=f"{W}x{H} K{K} B{B} {precision}", score_atol=1e-4)  # moderate |sim|: the north-star tolerance itself
         for s in ("0", "1"):
-            perm = None
-            rr = TA.check_keypoints(p["keypoints" + s][i], ref["keypoints" + s][0], ref["keypoint_scores" + s][0], ref["_nms_scores" + s][0], k_max=K)
+            rr = TA.check_keypoints(p["keypoints" + s][i], ref["keypoints" + s][0], ref["keypoint_scores" + s][0], ref["_nms_scores" + s][0],
+                                    got_scores=p["keypoint_scores" + s][i], k_max=K)
             ok = rr["perm"] >= 0
             torch.testing.assert_close(p["descriptors" + s][i][ok], ref["descriptors" + s][0][rr["perm"][ok]], rtol=0, atol=1e-4)
-            torch.testing.assert_close(p["keypoint_scores" + s][i][ok], ref["keypoint_scores" + s][0][rr["perm"][ok]], rtol=0, atol=TA.EPS_HEAT)
         assert r["m0"]["compared"] > K // 2
     return p
 

@@ -33,14 +33,15 @@ def test_keypoints_accepts_float_noise_rejects_real_errors():
     # float noise of the size the HIP path shows (<= EPS_HEAT per score): whatever moves is accepted as a near-tie
     moved = 0
     for seed in range(20):
-        noise = (torch.rand(ref["heatmap"].shape, generator=torch.Generator().manual_seed(seed)) * 2 - 1) * TA.EPS_HEAT
-        gk, _ = _detect(ref["heatmap"] + noise, k)
-        r = TA.check_keypoints(gk, rk, rs, nms, k_max=k)
+        noise = (torch.rand(ref["heatmap"].shape, generator=torch.Generator().manual_seed(seed)) * 2 - 1) * 3e-6
+        gk, gs = _detect(ref["heatmap"] + noise, k)
+        r = TA.check_keypoints(gk, rk, rs, nms, got_scores=gs, k_max=k)
+        assert r["eps"] <= 6.1e-6  # the near-tie width follows the measured score error of the image, not the global cap
         moved += r["rank_diffs"] + r["boundary_swaps"]
     # two keypoints with clearly different scores swapped: rejected
     gaps = (rs[:-1] - rs[1:])
     i = int(gaps.argmax())
-    assert gaps[i] > 10 * TA.EPS_KP
+    assert gaps[i] > 2 * TA.EPS_KP
     bad = rk.clone()
     bad[[i, i + 1]] = bad[[i + 1, i]]
     with pytest.raises(AssertionError, match="not a near-tie"):
