@@ -6,6 +6,7 @@
 
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <string>
@@ -74,6 +75,7 @@ struct LinLayer {
     int N = 0, K = 0, Npad = 0;
     float *W = nullptr, *bias = nullptr, *ps = nullptr, *pt = nullptr;
     float* Wh = nullptr;  // SH8 copy [K/16][Npad][64 B] for the f16x3 GEMM
+    float* Whp = nullptr;  // the same with the contraction index of every 32-block in accumulator order (ffn_f16.hip phase 3)
 };
 struct LgBlock {
     LinLayer proj;  // self: Wqkv (q|k|v rows), cross: [to_qk ; to_v]
@@ -242,7 +244,7 @@ int prep_conv3(mg_context* h, int which, const std::string& wkey, const std::str
 }
 
 // [N][K] -> [K/8][Npad][8]; `perm` optionally maps new row -> old row
-int prep_linear_rows(mg_context* h, const std::vector<const float*>& rows, const std::vector<float>& bias, int K, LinLayer* L) {
+int prep_linear_rows(mg_context* h, const std::vector<const float*>& rows, const std::vector<float>& bias, int K, LinLayer* L, bool kperm = false) {
     const int N = (int)rows.size();
     L->N = N;
     L->K = K;
@@ -265,6 +267,24 @@ int prep_linear_rows(mg_context* h, const std::vector<const float*>& rows, const
                 hp[row * 32 + grp * 16 + 8 + j] = lo;
             }
         if (int rc = upload(h, sh, &L->Wh)) return rc;
+        if (kperm && K % 512 == 0) {
+            // ffn_f16.hip phase 3: k-step j of the contraction is quarter j/8 of wave j%8, and position 8h + 4a + e inside it is hidden
+            // feature 64 (j%8) + 16 (j/8) + 8a + 4h + e -- the order in which the lanes' accumulator registers present the hidden row
+            std::fill(sh.begin(), sh.end(), 0.f);
+            for (int n = 0; n < N; ++n)
+                for (int kp = 0; kp < K; ++kp) {
+                    const int blk = kp / 512, kj = (kp % 512) >> 4, pp = kp & 15;
+                    const int ks = blk * 512 + 64 * (kj & 7) + 16 * (kj >> 3) + ((pp & 8) >> 1) + ((pp & 4) << 1) + (pp & 3);
+                    const float v = rows[n][ks];
+                    const _Float16 hi = (_Float16)v;
+                    const _Float16 lo = (_Float16)(v - (float)hi);
+                    const size_t row = (size_t)(kp >> 4) * L->Npad + n;
+                    const int grp = (kp >> 3) & 1, j = kp & 7;
+                    hp[row * 32 + grp * 16 + j] = hi;
+                    hp[row * 32 + grp * 16 + 8 + j] = lo;
+                }
+            if (int rc = upload(h, sh, &L->Whp)) return rc;
+        }
     }
     if (!bias.empty()) {
         std::vector<float> bp(L->Npad, 0.f);  // padded: a launch may round N up to a multiple of 32 (zero weights, zero bias)
@@ -274,13 +294,13 @@ int prep_linear_rows(mg_context* h, const std::vector<const float*>& rows, const
     return 0;
 }
 
-int prep_linear(mg_context* h, int which, const std::string& prefix, int N, int K, LinLayer* L) {
+int prep_linear(mg_context* h, int which, const std::string& prefix, int N, int K, LinLayer* L, bool kperm = false) {
     const HostTensor *w, *b;
     if (int rc = need(h, which, prefix + ".weight", {N, K}, &w)) return rc;
     if (int rc = need(h, which, prefix + ".bias", {N}, &b)) return rc;
     std::vector<const float*> rows(N);
     for (int n = 0; n < N; ++n) rows[n] = w->data.data() + (size_t)n * K;
-    return prep_linear_rows(h, rows, b->data, K, L);
+    return prep_linear_rows(h, rows, b->data, K, L, kperm);
 }
 
 // BatchNorm (eval) -> per-channel affine after the activation
@@ -381,7 +401,7 @@ int prep_ffn0_folded(mg_context* h, const std::string& p, const std::string& out
 
 int prep_ffn(mg_context* h, const std::string& p, LgBlock* blk) {
     if (int rc = prep_linear(h, 1, p + ".ffn.0", 512, 512, &blk->ffn0)) return rc;
-    if (int rc = prep_linear(h, 1, p + ".ffn.3", 256, 512, &blk->ffn3)) return rc;
+    if (int rc = prep_linear(h, 1, p + ".ffn.3", 256, 512, &blk->ffn3, true)) return rc;
     const HostTensor *g, *b;
     if (int rc = need(h, 1, p + ".ffn.1.weight", {512}, &g)) return rc;
     if (int rc = need(h, 1, p + ".ffn.1.bias", {512}, &b)) return rc;
@@ -470,7 +490,7 @@ int sg_bn(mg_context* h, int which, const std::string& prefix, int C, BnFold* ou
     return 0;
 }
 
-int sg_linear(mg_context* h, const std::vector<std::vector<double>>& W, const std::vector<double>& bias, int Kpad, LinLayer* L) {
+int sg_linear(mg_context* h, const std::vector<std::vector<double>>& W, const std::vector<double>& bias, int Kpad, LinLayer* L, bool kperm = false) {
     const int N = (int)W.size();
     std::vector<float> flat((size_t)N * Kpad, 0.f), bf(N);
     std::vector<const float*> rows(N);
@@ -479,11 +499,11 @@ int sg_linear(mg_context* h, const std::vector<std::vector<double>>& W, const st
         rows[n] = flat.data() + (size_t)n * Kpad;
         bf[n] = (float)bias[n];
     }
-    return prep_linear_rows(h, rows, bf, Kpad, L);
+    return prep_linear_rows(h, rows, bf, Kpad, L, kperm);
 }
 
 // Conv1d(k=1) `name` (N x K) with an optional BatchNorm1d `bn_name` folded in; K padded up to Kpad
-int sg_prep_conv(mg_context* h, int which, const std::string& name, int N, int K, const std::string& bn_name, int Kpad, LinLayer* out) {
+int sg_prep_conv(mg_context* h, int which, const std::string& name, int N, int K, const std::string& bn_name, int Kpad, LinLayer* out, bool kperm = false) {
     const HostTensor *w, *b;
     if (int rc = need(h, which, name + ".weight", {N, K, 1}, &w)) return rc;
     if (int rc = need(h, which, name + ".bias", {N}, &b)) return rc;
@@ -499,7 +519,7 @@ int sg_prep_conv(mg_context* h, int which, const std::string& name, int N, int K
         bias[n] = (double)b->data[n] * sc + t;
     }
     *out = LinLayer();
-    return sg_linear(h, W, bias, Kpad, out);
+    return sg_linear(h, W, bias, Kpad, out, kperm);
 }
 
 // MLP([cin, 32, 64, 128, 256, 256]) of the keypoint / endpoint encoders (superglue.py:89-97, gluestick.py:488-517)
@@ -554,7 +574,7 @@ int sg_prep_layer(mg_context* h, int which, const std::string& p, mg_context::Sg
         bias0[n] = bb * bn.s[n] + bn.t[n];
     }
     if (int rc = sg_linear(h, W0, bias0, 512, &L->mlp0f)) return rc;
-    return sg_prep_conv(h, which, p + ".mlp.3", 256, 512, "", 512, &L->mlp3);
+    return sg_prep_conv(h, which, p + ".mlp.3", 256, 512, "", 512, &L->mlp3, true);
 }
 
 int prepare_sg(mg_context* h, int n_layers) {
@@ -963,7 +983,18 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         launch_to_sh8(X, XS, (long long)T * 256, 1.f, s);
     }
 
+    // the three-launch form stays reachable for A/B timing (environment) and for the equivalence test (debug tap request)
+    static const bool unfused_env = getenv("MG_FFN_UNFUSED") != nullptr;
+    const bool unfused_ffn = unfused_env || h->taps.count("lg.unfused_ffn");
     auto ffn = [&](const LgBlock& blk) {
+        if (f16 && !unfused_ffn) {
+            ProfScope ps(h, s, "lg.ffn");
+            FfnF16Args a;
+            a.A0 = XS; a.A1 = CTX; a.W0 = blk.ffn0f.Wh; a.b0 = blk.ffn0f.bias; a.gamma = blk.ln_g; a.beta = blk.ln_b;
+            a.W3 = blk.ffn3.Whp; a.b3 = blk.ffn3.bias; a.X = X; a.XS = XS; a.T = (int)T; a.eps = 1e-5f; a.act = 0;
+            launch_ffn_f16x3(a, s);
+            return;
+        }
         {
             ProfScope ps(h, s, "lg.gemm.ffn0");
             if (f16) {
@@ -1179,6 +1210,16 @@ struct GnnRun {
                 a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
                 launch_attention(a, s);
             }
+        }
+        static const bool unfused_env = getenv("MG_FFN_UNFUSED") != nullptr;
+        const bool unfused_ffn = unfused_env || h->taps.count("lg.unfused_ffn");
+        if (f16 && !unfused_ffn) {
+            ProfScope ps(h, s, t + ".ffn");
+            FfnF16Args a;
+            a.A0 = XS; a.A1 = CTX; a.W0 = Lr.mlp0f.Wh; a.b0 = Lr.mlp0f.bias; a.W3 = Lr.mlp3.Whp; a.b3 = Lr.mlp3.bias;
+            a.X = X; a.XS = XS; a.T = (int)T; a.act = 1;
+            launch_ffn_f16x3(a, s);
+            return;
         }
         {
             ProfScope ps(h, s, t + ".gemm.mlp0");

@@ -114,6 +114,24 @@ void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s);
 void launch_to_sh8(const float* in, void* out, long long elems, float scale, hipStream_t s);  // SH8(in * scale)
 void launch_from_sh8(const void* in, float* out, long long elems, hipStream_t s);          // hi + lo back to fp32
 
+// ---- ffn_f16.hip : x += W3 . act(W0f . [x | ctx] + b0) + b3 in one kernel (f16x3 mode) ------------------------------
+struct FfnF16Args {
+    const void* A0 = nullptr;    // SH8 (T,256): the residual stream (k 0..255 of ffn.0)
+    const void* A1 = nullptr;    // SH8 (T,256): attention context (k 256..511; the out-projection is folded into W0)
+    const void* W0 = nullptr;    // SH8 tiled [512/16][512][64 B]
+    const float* b0 = nullptr;   // (512)
+    const float* gamma = nullptr;  // LayerNorm affine (512), act == 0 only
+    const float* beta = nullptr;
+    const void* W3 = nullptr;    // SH8 tiled [512/16][256][64 B], contraction index in accumulator order (api.hip: kperm)
+    const float* b3 = nullptr;   // (256)
+    float* X = nullptr;          // fp32 residual stream (T,256), updated in place
+    void* XS = nullptr;          // its SH8 copy, rewritten
+    int T = 0;
+    float eps = 1e-5f;
+    int act = 0;                 // 0: LayerNorm + GELU(erf) (LightGlue), 1: ReLU (SuperGlue / GlueStick, BatchNorm folded)
+};
+void launch_ffn_f16x3(const FfnF16Args& a, hipStream_t s);
+
 // ---- sp_post.hip ---------------------------------------------------------------------------------
 void launch_softmax_d2s(const float* logits, int ld, int B, int hc, int wc, float* heat, hipStream_t s);
 void launch_l2norm_rows(float* x, long long rows, int dim, hipStream_t s);

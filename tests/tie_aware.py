@@ -176,9 +176,11 @@ def check_two_view(p, ref, b, k_max, th, tag="", la_floor=1e-5, score_atol=None)
     out["eps_la"] = eps
     out["m0"] = check_matches(p["matches0"][b, :M], ref["matches0"][0], S, th, eps, perms[0], perms[1])
     out["m1"] = check_matches(p["matches1"][b, :N], ref["matches1"][0], S.t(), th, eps, perms[1], perms[0])
-    # scores where both sides made the same assignment
-    inv1 = {int(v): j for j, v in enumerate(perms[1].tolist()) if v >= 0}
-    worst = 0.0
+    # scores where both sides made the same assignment.  The reference keeps exp(row max) as the score of a row that is
+    # mutual but below the filter threshold (match -1, lightglue.py:296-300) and 0 for a non-mutual row, so two unmatched
+    # rows may still differ in score when the MUTUAL check itself was a near-tie: accepted only with that proof.
+    m_row, m_col, _ = match_margins(S, th)
+    worst, worst_at, mutual_flips = 0.0, None, 0
     for i_h in range(M):
         i = int(perms[0][i_h])
         if i < 0:
@@ -187,10 +189,20 @@ def check_two_view(p, ref, b, k_max, th, tag="", la_floor=1e-5, score_atol=None)
         j_ref = int(ref["matches0"][0, i])
         if (j_h < 0) != (j_ref < 0) or (j_h >= 0 and int(perms[1][j_h]) != j_ref):
             continue
-        worst = max(worst, abs(float(p["matching_scores0"][b, i_h]) - float(ref["matching_scores0"][0, i])))
+        s_h, s_r = float(p["matching_scores0"][b, i_h]), float(ref["matching_scores0"][0, i])
+        if j_ref < 0 and (s_h == 0.0) != (s_r == 0.0):
+            js = int(S[i, :N].argmax())
+            assert min(float(m_row[i, js]), float(m_col[i, js])) < eps, f"row {i}: mutual check differs (scores {s_h} vs {s_r}) without a near-tie"
+            mutual_flips += 1
+            continue
+        d = abs(s_h - s_r)
+        if d > worst:
+            worst, worst_at = d, (i, j_ref, s_h, s_r)
+    out["mutual_flips"] = mutual_flips
     if score_atol is None:
         score_atol = max(1e-4, 1.2 * out.get("la_err", 0.0))
-    assert worst <= score_atol, f"matching_scores0 differ by {worst:.2e} (> {score_atol:.1e}) where the assignment agrees"
+    assert worst <= score_atol, (f"matching_scores0 differ by {worst:.2e} (> {score_atol:.1e}) where the assignment agrees: (row, col, hip, oracle) = {worst_at}, "
+                                 f"log_assignment error {out.get('la_err')}")
     out["score_err"] = worst
     print(f"[tie-aware{' ' + tag if tag else ''}] pair {b}: keypoints0 {out['kp0']}, keypoints1 {out['kp1']}; "
           f"matches0 {out['m0']}, matches1 {out['m1']} (eps_la {eps:.2e}, la err {out.get('la_err', float('nan')):.2e}, score err {worst:.2e})")
