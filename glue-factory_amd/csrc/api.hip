@@ -992,6 +992,11 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
             FfnF16Args a;
             a.A0 = XS; a.A1 = CTX; a.W0 = blk.ffn0f.Wh; a.b0 = blk.ffn0f.bias; a.gamma = blk.ln_g; a.beta = blk.ln_b;
             a.W3 = blk.ffn3.Whp; a.b3 = blk.ffn3.bias; a.X = X; a.XS = XS; a.T = (int)T; a.eps = 1e-5f; a.act = 0;
+            auto st = h->taps.find("ffn.stamps");  // diagnostic: per-workgroup phase stamps of the last launch
+            if (st != h->taps.end()) {
+                const size_t n = (T + 127) / 128 * 8;
+                if (st->second.ensure(n * sizeof(float)) == 0) { a.stamps = st->second.f(); h->tap_count["ffn.stamps"] = n; }
+            }
             launch_ffn_f16x3(a, s);
             return;
         }

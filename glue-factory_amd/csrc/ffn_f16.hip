@@ -9,38 +9,44 @@
 //
 // One workgroup (8 waves) owns a tile of 128 tokens:
 //   phase 1  H[512 x 128] = W0f . A^T : wave w accumulates hidden features [64w, 64w+64) x 128 tokens (8 MFMA tiles, 128
-//            accumulator registers); K = 512 in stages of 16, token rows (HBM) and weight rows (L2) arrive by LDS-DMA
-//            into rings of their own depth, issued by different waves (vmcnt retires in order), as in gemm_f16.hip.
+//            accumulator registers); K = 512 in stages of 16.  Token rows (HBM) and weight rows (L2) arrive by LDS-DMA in
+//            three-slot rings; every wave issues its share (1 + 4 pieces of 1 KB per stage) BETWEEN its MFMAs, three stages
+//            ahead, and reads the fragments of stage k+1 into a second register set while the MFMAs of stage k run -- one
+//            barrier per stage, and nothing between the barrier and the first MFMA but one DMA issue.
 //   phase 2  bias, LayerNorm over the 512 features of a token (two passes: sum, then sum of squared deviations; the
-//            8 waves' partial sums meet in LDS and are added in wave order), GELU(erf) -- all on the accumulator registers.
+//            8 waves' partial sums meet in LDS and are added in wave order), GELU(erf), split into fp16 halves -- all on
+//            the accumulator registers.
 //   phase 3  OUT[256 x 128] = W3 . H'^T : the hidden features are now the contraction index, and they are spread over the
 //            waves.  They go through LDS one k-step (16 features x 128 tokens, 8 KB) at a time, in a ring of 8 slots: a
 //            wave's 64 x 128 block is four k-steps ("quarters"); k-step j of the contraction is quarter j/8 of wave j%8, so
-//            every wave writes its first quarter before the loop and one more quarter every eighth iteration, seven
-//            iterations ahead of its use, under the other waves' MFMAs -- and a quarter's 32 registers are dead once written,
-//            which keeps the loop at 96 + 64 accumulator registers.  Wave (wf, wt) accumulates output features
-//            [64 wf, +64) x tokens [64 wt, +64).  An accumulator register block of a lane is used as it stands:
-//            registers 8s..8s+7 of lane (token j, half h) become the 16-byte fragment of half h -- which fixes the order of
-//            the contraction index: position 8h + 4a + e of k-step j is hidden feature 64 (j%8) + 16 (j/8) + 8a + 4h + e;
-//            W3 is tiled in that order at upload (api.hip: kperm).
+//            every wave writes its first quarter before the loop and one more quarter every eighth iteration, eight
+//            k-steps ahead of its use, under the other waves' MFMAs -- and a quarter's 32 registers are dead once written.
+//            Wave (wf, wt) accumulates output features [64 wf, +64) x tokens [64 wt, +64).  An accumulator register block
+//            of a lane is used as it stands: registers 8s..8s+7 of lane (token j, half h) become the 16-byte fragment of
+//            half h -- which fixes the order of the contraction index: position 8h + 4a + e of k-step j is hidden feature
+//            64 (j%8) + 16 (j/8) + 8a + 4h + e; W3 is tiled in that order at upload (api.hip: kperm).  Same pipeline as
+//            phase 1 (W3 stages by LDS-DMA, fragments of k-step k+1 read under the MFMAs of k-step k); the residual rows
+//            are fetched under the last eight k-steps, when the hidden block's registers are free.
 //   epilogue as in gemm_f16.hip: + b3, + residual, fp32 row and its SH8 copy, quad-transposed full-line stores.
 #include "common.h"
 #include "kernels.h"
+
+#include <type_traits>
 
 namespace {
 
 constexpr int FT = 512;                  // threads: 8 waves
 constexpr int TMF = 128;                 // tokens per workgroup
 constexpr int HID = 512, DOUT = 256;     // hidden width, output width
-constexpr int TS1 = 5, WS1 = 3;          // phase-1 rings: token stages (8 KB) / weight stages (32 KB)
-constexpr int WS3 = 4;                   // phase-3 weight ring (16 KB stages)
+constexpr int RS = 3;                    // phase-1 DMA ring slots (stage k+3 is issued into the slot stage k just left)
+constexpr int RS3 = 4;                   // phase-3 W3 ring slots (two stages per barrier interval)
+constexpr int HR = 8;                    // H' ring: k-steps of 128 tokens x 64 B
 
 constexpr int TOK_STAGE = TMF * 4;       // u32x4 per stage
 constexpr int W1_STAGE = HID * 4;
 constexpr int W3_STAGE = DOUT * 4;
-constexpr int HR = 8;                    // H' ring: k-steps of 128 tokens x 64 B
-constexpr int RING1 = TS1 * TOK_STAGE + WS1 * W1_STAGE;  // u32x4
-constexpr int RING3 = HR * TOK_STAGE + WS3 * W3_STAGE;
+constexpr int RING1 = RS * (TOK_STAGE + W1_STAGE);  // u32x4
+constexpr int RING3 = HR * TOK_STAGE + RS3 * W3_STAGE;
 constexpr int RING = RING1 > RING3 ? RING1 : RING3;
 constexpr int NPAR = 3 * HID + DOUT;     // b0 | gamma | beta | b3
 constexpr int NSTAT = 2 * 8 * TMF;       // partial sums / partial squared deviations per wave and token
@@ -49,28 +55,19 @@ __device__ __forceinline__ int swz(int row, int q) { return row * 4 + (q ^ ((row
 
 template <int N>
 __device__ __forceinline__ void wait_vm() {
-    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-    else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-    else if constexpr (N == 12) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-    else if constexpr (N == 16) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-// wait until all but `stages` younger stages (of `per` pieces each) of this wave's DMA stream have landed
-template <int per>
-__device__ __forceinline__ void wait_stages(int ahead) {
-    if (ahead >= 3) { if constexpr (per * 3 <= 16) wait_vm<per * 3>(); else wait_vm<16>(); }
-    else if (ahead == 2) wait_vm<per * 2>();
-    else if (ahead == 1) wait_vm<per>();
-    else wait_vm<0>();
-}
-
-// LDS writes of this wave are complete, then the workgroup barrier (the raw s_barrier does not wait for them; DMA stays in flight)
+__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// LDS accesses of this wave are complete, then the workgroup barrier (the raw s_barrier does not wait for them; DMA stays in flight)
 __device__ __forceinline__ void lds_barrier() {
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    wait_lds();
     __builtin_amdgcn_s_barrier();
 }
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+#ifndef MG_FFN_EXP  // timing ablations only (wrong results, finite values): bit 0/1 no DMA in the phase-3/1 loop, 2/5 no barriers, 3 no quarter writes
+#define MG_FFN_EXP 0
+#endif
+constexpr int EXP = MG_FFN_EXP;
 
 enum { ACT_LN_GELU = 0, ACT_RELU = 1 };
 
@@ -97,7 +94,9 @@ __device__ __forceinline__ float erf_select(float x) {
     return copysignf(ax < 1.f ? r1 : r2, x);
 }
 
-template <int ACT>
+// STAMP: diagnostic instantiation only (debug tap "ffn.stamps"): wave 0 of every workgroup records s_memtime at the phase
+// boundaries, as cycle counts relative to its start, into a buffer nothing else reads.  The production kernel holds no stamp.
+template <int ACT, bool STAMP>
 __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
     __shared__ u32x4 s_ring[RING + (NPAR + NSTAT) / 4];
     float* const s_par = reinterpret_cast<float*>(s_ring + RING);
@@ -107,8 +106,15 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
     const int wu = __builtin_amdgcn_readfirstlane(t >> 6);
     const int i32 = lane & 31, h = lane >> 5;
     const int m0 = blockIdx.x * TMF;
-    const bool tok_wave = wu < 4;
-    const int lw = wu & 3;
+    unsigned long long t_start = 0;
+    auto stamp = [&](int slot) {
+        if constexpr (STAMP) {
+            const unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (slot == 0) t_start = now;
+            if (t == 0) p.stamps[blockIdx.x * 8 + slot] = (float)(now - t_start);
+        }
+    };
+    stamp(0);
 
     // 16-byte piece index of this lane's hi / lo fragment inside a tile whose first row is a multiple of 16
     const int lane_hi = swz(i32, 2 * h), lane_lo = swz(i32, 2 * h + 1);
@@ -118,30 +124,40 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
     const u32x4* W0 = reinterpret_cast<const u32x4*>(p.W0);
     const u32x4* W3 = reinterpret_cast<const u32x4*>(p.W3);
 
+    // per-feature parameters -> LDS by DMA as well (a plain load here would make hipcc drain the whole DMA prologue at its use)
+    {
+        u32x4* dst = s_ring + RING;
+        const int piece = wu;  // 7 pieces of 1 KB: b0 (2), gamma (2), beta (2), b3 (1)
+        const float* src = nullptr;
+        if (piece < 2) src = p.b0 + piece * 256;
+        else if (piece < 4) src = ACT == ACT_LN_GELU ? p.gamma + (piece - 2) * 256 : nullptr;
+        else if (piece < 6) src = ACT == ACT_LN_GELU ? p.beta + (piece - 4) * 256 : nullptr;
+        else if (piece == 6) src = p.b3;
+        if (src) __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(src) + lane, dst + piece * 64, 16, 0, 0);
+    }
+
     // ---- phase 1: H = W0f . A^T ----------------------------------------------------------------------------------
     u32x4* const s_tok = s_ring;
-    u32x4* const s_w1 = s_ring + TS1 * TOK_STAGE;
-    auto issue_tok = [&](int kt) {  // 128 rows x 64 B = 8 pieces of 1 KB: waves 0-3, two each
-        const int k0 = kt * 16;
-        const u32x4* src = k0 < 256 ? A0 : A1;
-        const int kk = k0 & 255;
-        u32x4* ring = s_tok + (kt % TS1) * TOK_STAGE;
+    u32x4* const s_w1 = s_ring + RS * TOK_STAGE;
+    // DMA sources of this lane: token piece wu (rows 16 wu ..), weight pieces 4 wu + j; the LDS image is linear, the XOR swizzle
+    // is applied to the source piece
+    long long tok_off;
+    int w_off[4];
+    {
+        const int slot = wu * 64 + lane, row = slot >> 2, q = (slot & 3) ^ ((row >> 2) & 3);
+        tok_off = (long long)min(m0 + row, p.T - 1) * 64 + q;
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int slot = (lw * 2 + j) * 64 + lane, row = slot >> 2, qp = slot & 3;
-            const int q = qp ^ ((row >> 2) & 3);
-            const int gm = min(m0 + row, p.T - 1);
-            __builtin_amdgcn_global_load_lds(src + (((long long)gm * 256 + kk) >> 2) + q, ring + (lw * 2 + j) * 64, 16, 0, 0);
+        for (int j = 0; j < 4; ++j) {
+            const int sl = (wu * 4 + j) * 64 + lane, r = sl >> 2;
+            w_off[j] = r * 4 + ((sl & 3) ^ ((r >> 2) & 3));
         }
+    }
+    auto dma_tok = [&](int kt) {
+        const u32x4* src = (kt < 16 ? A0 : A1) + tok_off + (kt & 15) * 4;
+        __builtin_amdgcn_global_load_lds(src, s_tok + (kt % RS) * TOK_STAGE + wu * 64, 16, 0, 0);
     };
-    auto issue_w1 = [&](int kt) {  // 512 rows x 64 B = 32 pieces: waves 4-7, eight each
-        u32x4* ring = s_w1 + (kt % WS1) * W1_STAGE;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int slot = (lw * 8 + j) * 64 + lane, row = slot >> 2, qp = slot & 3;
-            const int q = qp ^ ((row >> 2) & 3);
-            __builtin_amdgcn_global_load_lds(W0 + ((long long)kt * HID + row) * 4 + q, ring + (lw * 8 + j) * 64, 16, 0, 0);
-        }
+    auto dma_w1 = [&](int kt, int j) {
+        __builtin_amdgcn_global_load_lds(W0 + (long long)kt * W1_STAGE + w_off[j], s_w1 + (kt % RS) * W1_STAGE + (wu * 4 + j) * 64, 16, 0, 0);
     };
 
     f32x16 acc[2][4];  // [hidden tile of this wave][token tile]
@@ -153,76 +169,78 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     constexpr int NK1 = HID / 16;  // K of ffn.0 = 512
-    if (tok_wave) {
-#pragma unroll 1
-        for (int s0 = 0; s0 < TS1 - 1; ++s0) issue_tok(s0);
-    } else {
-#pragma unroll 1
-        for (int s0 = 0; s0 < WS1 - 1; ++s0) issue_w1(s0);
-    }
-    for (int i = t; i < NPAR; i += FT) {
-        float v;
-        if (i < HID) v = p.b0[i];
-        else if (i < 2 * HID) v = ACT == ACT_LN_GELU ? p.gamma[i - HID] : 1.f;
-        else if (i < 3 * HID) v = ACT == ACT_LN_GELU ? p.beta[i - 2 * HID] : 0.f;
-        else v = p.b3[i - 3 * HID];
-        s_par[i] = v;
-    }
-#pragma unroll 1
-    for (int kt = 0; kt < NK1; ++kt) {
-        if (tok_wave) wait_stages<2>(min(TS1 - 2, NK1 - 1 - kt));
-        else wait_stages<8>(min(WS1 - 2, NK1 - 1 - kt));
-        __builtin_amdgcn_s_barrier();
-        if (tok_wave) {
-            if (kt + TS1 - 1 < NK1) issue_tok(kt + TS1 - 1);
-        } else {
-            if (kt + WS1 - 1 < NK1) issue_w1(kt + WS1 - 1);
-        }
-        // all fragment addresses are (per-lane base) + (compile-time constant): rows 32 apart share the swizzle term
-        const f16x8* st = reinterpret_cast<const f16x8*>(s_tok + (kt % TS1) * TOK_STAGE);
-        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w1 + (kt % WS1) * W1_STAGE) + wu * 64 * 4;
-        f16x8 ah[2], al[2], bh[4], bl[4];
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
-            ah[ft] = sw[lane_hi + ft * 32 * 4];
-            al[ft] = sw[lane_lo + ft * 32 * 4];
-        }
+    for (int s0 = 0; s0 < RS; ++s0) {
+        dma_tok(s0);
 #pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-            bh[tt] = st[lane_hi + tt * 32 * 4];
-            bl[tt] = st[lane_lo + tt * 32 * 4];
-        }
+        for (int j = 0; j < 4; ++j) dma_w1(s0, j);
+    }
+    f16x8 ah[2][2], al[2][2], bh[2][4], bl[2][4];  // [register set][tile]
+    auto read1 = [&](int set, int kt, int i) {  // fragment read i (0..11) of stage kt: lo halves last (they are used last)
+        const f16x8* st = reinterpret_cast<const f16x8*>(s_tok + (kt % RS) * TOK_STAGE);
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w1 + (kt % RS) * W1_STAGE) + wu * 64 * 4;
+        if (i < 2) ah[set][i] = sw[lane_hi + i * 32 * 4];
+        else if (i < 6) bh[set][i - 2] = st[lane_hi + (i - 2) * 32 * 4];
+        else if (i < 10) bl[set][i - 6] = st[lane_lo + (i - 6) * 32 * 4];
+        else al[set][i - 10] = sw[lane_lo + (i - 10) * 32 * 4];
+    };
+    wait_vm<10>();  // parameters + stage 0 (issued first) have landed
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 12; ++i) read1(0, 0, i);
+
+    // one stage: [my pieces of stage kt+1 landed] [my reads of stage kt done] barrier, then the MFMAs of stage kt with, between
+    // them, the DMA of stage kt+3 (into the slot stage kt just left) and the fragment reads of stage kt+1 (other register set)
+    auto stage1 = [&](auto set_c, int kt) {
+        constexpr int S = decltype(set_c)::value;
+        if (kt + 2 <= NK1 - 1) wait_vm<5>(); else wait_vm<0>();
+        if (!(EXP & 32)) lds_barrier();
+        const bool more_dma = kt + RS < NK1 && !(EXP & 2), more_rd = kt + 1 < NK1;
+        // 24 MFMAs in product-major order (hi.hi, hi.lo, lo.hi; consecutive MFMAs hit different accumulators).  The head is
+        // MFMA-only (the pipe starts the moment the barrier opens); from the third on, every MFMA is followed by ONE other
+        // instruction -- the five DMA pieces of stage kt+3, then the twelve fragment reads of stage kt+1 -- which issue in its shadow.
+        int slot_i = 0;
+        auto filler = [&]() {
+            const int f = slot_i++ - 2;
+            if (f >= 0 && f < 5) { if (more_dma) { if (f == 0) dma_tok(kt + RS); else dma_w1(kt + RS, f - 1); } }
+            else if (f >= 5 && f < 17) { if (more_rd) read1(1 - S, kt + 1, f - 5); }
+            PIN();
+        };
+        PIN();
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[ft][tt] = mfma16(ah[ft], bh[tt], acc[ft][tt]);
+            for (int tt = 0; tt < 4; ++tt) { acc[ft][tt] = mfma16(ah[S][ft], bh[S][tt], acc[ft][tt]); filler(); }
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[ft][tt] = mfma16(ah[ft], bl[tt], acc[ft][tt]);
+            for (int tt = 0; tt < 4; ++tt) { acc[ft][tt] = mfma16(ah[S][ft], bl[S][tt], acc[ft][tt]); filler(); }
 #pragma unroll
         for (int ft = 0; ft < 2; ++ft)
 #pragma unroll
-            for (int tt = 0; tt < 4; ++tt) acc[ft][tt] = mfma16(al[ft], bh[tt], acc[ft][tt]);
+            for (int tt = 0; tt < 4; ++tt) { acc[ft][tt] = mfma16(al[S][ft], bh[S][tt], acc[ft][tt]); filler(); }
+    };
+#pragma unroll 1
+    for (int kt = 0; kt < NK1; kt += 2) {
+        stage1(std::integral_constant<int, 0>{}, kt);
+        stage1(std::integral_constant<int, 1>{}, kt + 1);
     }
-    __builtin_amdgcn_s_barrier();  // every wave has read its last phase-1 fragments: the rings may be re-used
+    lds_barrier();  // every wave has read its last phase-1 fragments: the rings may be re-used
+    stamp(1);
 
     // ---- phase 3 set-up: W3 stream starts now, under the LayerNorm / GELU arithmetic ---------------------------------
     u32x4* const s_h = s_ring;                      // H' ring
     u32x4* const s_w3 = s_ring + HR * TOK_STAGE;
     constexpr int NK3 = HID / 16;
-    auto issue_w3 = [&](int kt) {  // 256 rows x 64 B = 16 pieces: waves 4-7, four each
-        u32x4* ring = s_w3 + (kt % WS3) * W3_STAGE;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int slot = (lw * 4 + j) * 64 + lane, row = slot >> 2, qp = slot & 3;
-            const int q = qp ^ ((row >> 2) & 3);
-            __builtin_amdgcn_global_load_lds(W3 + ((long long)kt * DOUT + row) * 4 + q, ring + (lw * 4 + j) * 64, 16, 0, 0);
-        }
+    auto dma_w3 = [&](int kt, int j) {  // 256 rows x 64 B = 16 pieces: two per wave (rows of pieces 2 wu + j: the first 128 rows of w_off's map)
+        const int sl = (wu * 2 + j) * 64 + lane, r = sl >> 2;
+        const int off = r * 4 + ((sl & 3) ^ ((r >> 2) & 3));
+        __builtin_amdgcn_global_load_lds(W3 + (long long)kt * W3_STAGE + off, s_w3 + (kt % RS3) * W3_STAGE + (wu * 2 + j) * 64, 16, 0, 0);
     };
-    if (!tok_wave) {
-#pragma unroll 1
-        for (int s0 = 0; s0 < WS3 - 1; ++s0) issue_w3(s0);
+#pragma unroll
+    for (int s0 = 0; s0 < 3; ++s0) {
+        dma_w3(s0, 0);
+        dma_w3(s0, 1);
     }
 
     // ---- phase 2: bias, LayerNorm, GELU (or bias, ReLU) on the accumulators -------------------------------------------
@@ -306,23 +324,34 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[ft][tt][r] = fmaxf(acc[ft][tt][r], 0.f);
     }
-
-    // quarter q = 2 ft + s of this wave's block -> ring slot: piece 2h / 2h+1 of a token row = hi / lo halves of registers 8s..8s+7
+    stamp(2);
+    // Split into fp16 halves HERE, by all waves at once: in the loop below a quarter is written by one wave per iteration while the
+    // other seven wait for it at the next barrier, so that write must be nothing but eight LDS stores.
+    // Quarter q = 2 ft + s of this wave's block = registers 8s..8s+7 of acc[ft][*]: hi / lo become pieces 2h / 2h+1 of a token row.
+    f16x8 Hh[4][4], Hl[4][4];  // [quarter][token tile]
+#pragma unroll
+    for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int tt = 0; tt < 4; ++tt) {
+                const f32x8 v = {acc[ft][tt][8 * s], acc[ft][tt][8 * s + 1], acc[ft][tt][8 * s + 2], acc[ft][tt][8 * s + 3],
+                                 acc[ft][tt][8 * s + 4], acc[ft][tt][8 * s + 5], acc[ft][tt][8 * s + 6], acc[ft][tt][8 * s + 7]};
+                split8(v, Hh[2 * ft + s][tt], Hl[2 * ft + s][tt]);
+                // materialise the halves now: without this hipcc sinks the GELU + split of the later quarters into the
+                // (single-wave) write blocks of the loop below, where seven waves would wait for it
+                asm volatile("" : "+v"(Hh[2 * ft + s][tt]), "+v"(Hl[2 * ft + s][tt]));
+            }
     auto write_quarter = [&](int q, int slot) {
-        const int ft = q >> 1, s = q & 1;
         f16x8* dst = reinterpret_cast<f16x8*>(s_h + slot * TOK_STAGE);
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
-            const f32x8 v = {acc[ft][tt][8 * s], acc[ft][tt][8 * s + 1], acc[ft][tt][8 * s + 2], acc[ft][tt][8 * s + 3],
-                             acc[ft][tt][8 * s + 4], acc[ft][tt][8 * s + 5], acc[ft][tt][8 * s + 6], acc[ft][tt][8 * s + 7]};
-            f16x8 hi, lo;
-            split8(v, hi, lo);
-            dst[lane_hi + tt * 32 * 4] = hi;
-            dst[lane_lo + tt * 32 * 4] = lo;
+            dst[lane_hi + tt * 32 * 4] = Hh[q][tt];
+            dst[lane_lo + tt * 32 * 4] = Hl[q][tt];
         }
     };
     write_quarter(0, wu);  // k-steps 0..7
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // visible to the other waves behind the first barrier of the loop
+    stamp(3);
 
     // ---- phase 3: OUT = W3 . H'^T ---------------------------------------------------------------------------------------
     const int wf3 = wu >> 1, wt3 = wu & 1;
@@ -333,32 +362,90 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
         for (int j = 0; j < 2; ++j)
 #pragma unroll
             for (int r = 0; r < 16; ++r) o[i][j][r] = 0.f;
-#pragma unroll
-    for (int kt = 0; kt < NK3; ++kt) {  // fully unrolled: which quarter is written where is a compile-time fact
-        if (!tok_wave) wait_stages<4>(min(WS3 - 2, NK3 - 1 - kt));
-        __builtin_amdgcn_s_barrier();  // W3 stage kt landed; H' k-step kt complete (written >= 7 iterations ago); slot of k-step kt-1 is free
-        if (!tok_wave && kt + WS3 - 1 < NK3) issue_w3(kt + WS3 - 1);
-        if (kt >= 1 && kt + HR - 1 < NK3 && wu == ((kt + HR - 1) & 7)) write_quarter((kt + HR - 1) >> 3, (kt + HR - 1) % HR);
+    f16x8 ch[2][2], cl[2][2], dh[2][2], dl[2][2];  // [register set][tile]: W3 (c) and H' (d) fragments
+    auto read3 = [&](int set, int kt, int i) {  // fragment read i (0..7) of k-step kt, in the order the MFMAs need them
         const f16x8* sh = reinterpret_cast<const f16x8*>(s_h + (kt % HR) * TOK_STAGE) + wt3 * 64 * 4;
-        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w3 + (kt % WS3) * W3_STAGE) + wf3 * 64 * 4;
-        f16x8 bh[2], bl[2];
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w3 + (kt % RS3) * W3_STAGE) + wf3 * 64 * 4;
+        if (i == 0) ch[set][0] = sw[lane_hi];
+        else if (i == 1) dh[set][0] = sh[lane_hi];
+        else if (i == 2) dh[set][1] = sh[lane_hi + 32 * 4];
+        else if (i == 3) ch[set][1] = sw[lane_hi + 32 * 4];
+        else if (i == 4) dl[set][0] = sh[lane_lo];
+        else if (i == 5) dl[set][1] = sh[lane_lo + 32 * 4];
+        else if (i == 6) cl[set][0] = sw[lane_lo];
+        else cl[set][1] = sw[lane_lo + 32 * 4];
+    };
+    auto write_piece = [&](int q, int slot, int i) {  // store i (0..7) of quarter q
+        f16x8* dst = reinterpret_cast<f16x8*>(s_h + slot * TOK_STAGE);
+        if (i & 1) dst[lane_lo + (i >> 1) * 32 * 4] = Hl[q][i >> 1];
+        else dst[lane_hi + (i >> 1) * 32 * 4] = Hh[q][i >> 1];
+    };
+    wait_vm<4>();  // W3 stage 0 (stages 1, 2 stay in flight)
+    lds_barrier(); // ... and everybody's first quarter
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            bh[tt] = sh[lane_hi + tt * 32 * 4];
-            bl[tt] = sh[lane_lo + tt * 32 * 4];
-        }
+    for (int i = 0; i < 8; ++i) read3(0, 0, i);
+    float resid[2][2][16];
+    // Two k-steps per barrier interval (a = 2j from register set 0, b = 2j+1 from set 1): a 12-MFMA k-step is too short to pay for a
+    // barrier of its own (measured: 29 % of this phase).  At the barrier of interval j every wave's pieces of stages 2j+1, 2j+2 have
+    // landed and the reads of k-steps <= 2j are done, so: DMA stages 2j+3, 2j+4 into the slots of stages 2j-1, 2j; k-steps 2j+7 and
+    // 2j+8 of the hidden block into the slots of k-steps 2j-1 and 2j, by their owner waves.  Fully unrolled: which quarter goes where is
+    // a compile-time fact.  12 MFMAs per k-step, MFMA-first, four accumulators in rotation; every later MFMA carries one filler.
+    auto kstep = [&](int S, int kt, int j, bool second) {
+        const int rd_kt = kt + 1;                    // fragments to fetch under these MFMAs (into the other register set)
+        const int wr_kt = second ? 2 * j + 8 : 2 * j + 7;  // hidden k-step to publish (pre-loop wrote 0..7)
+        const bool writer = wr_kt >= HR && wr_kt < NK3 && wu == (wr_kt & 7) && !(EXP & 8);
+        int slot_i = 0;
+        auto filler = [&]() {
+            const int f = slot_i++ - 1;
+            // both stages' DMA right behind the barrier (they must land by the next one), then the fragment reads
+            if (!second && f >= 0 && f < 2) {
+                if (2 * j + 3 + f < NK3 && !(EXP & 1)) { dma_w3(2 * j + 3 + f, 0); dma_w3(2 * j + 3 + f, 1); }
+            }
+            const int r = second ? f : f - 2;
+            if (r >= 0 && r < 8) {
+                if (rd_kt < NK3) read3(1 - S, rd_kt, r);
+                if (writer) write_piece(wr_kt >> 3, wr_kt % HR, r);
+            }
+            PIN();
+        };
+        o[0][0] = mfma16(ch[S][0], dh[S][0], o[0][0]); filler();
+        o[0][1] = mfma16(ch[S][0], dh[S][1], o[0][1]); filler();
+        o[1][0] = mfma16(ch[S][1], dh[S][0], o[1][0]); filler();
+        o[1][1] = mfma16(ch[S][1], dh[S][1], o[1][1]); filler();
+        o[0][0] = mfma16(ch[S][0], dl[S][0], o[0][0]); filler();
+        o[0][1] = mfma16(ch[S][0], dl[S][1], o[0][1]); filler();
+        o[1][0] = mfma16(ch[S][1], dl[S][0], o[1][0]); filler();
+        o[1][1] = mfma16(ch[S][1], dl[S][1], o[1][1]); filler();
+        o[0][0] = mfma16(cl[S][0], dh[S][0], o[0][0]); filler();
+        o[0][1] = mfma16(cl[S][0], dh[S][1], o[0][1]); filler();
+        o[1][0] = mfma16(cl[S][1], dh[S][0], o[1][0]); filler();
+        o[1][1] = mfma16(cl[S][1], dh[S][1], o[1][1]); filler();
+    };
 #pragma unroll
-        for (int ft = 0; ft < 2; ++ft) {
-            const f16x8 ah = sw[lane_hi + ft * 32 * 4], al = sw[lane_lo + ft * 32 * 4];
-            o[ft][0] = mfma16(ah, bh[0], o[ft][0]);
-            o[ft][1] = mfma16(ah, bh[1], o[ft][1]);
-            o[ft][0] = mfma16(ah, bl[0], o[ft][0]);
-            o[ft][1] = mfma16(ah, bl[1], o[ft][1]);
-            o[ft][0] = mfma16(al, bh[0], o[ft][0]);
-            o[ft][1] = mfma16(al, bh[1], o[ft][1]);
+    for (int j = 0; j < NK3 / 2; ++j) {
+        wait_vm<0>();  // stages 2j+1, 2j+2 (and, once, the residual rows) -- everything this wave has in flight
+        if (!(EXP & 4)) lds_barrier();
+        PIN();
+        if (j == NK3 / 2 - 3) {  // the hidden block's registers are free from here on: fetch the residual rows under the last MFMAs
+#pragma unroll
+            for (int ft = 0; ft < 2; ++ft)
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const int tok = min(m0 + wt3 * 64 + tt * 32 + i32, p.T - 1);
+                    const float* rs = p.X + (long long)tok * DOUT + wf3 * 64 + ft * 32 + 16 * h;
+#pragma unroll
+                    for (int jj = 0; jj < 16; jj += 4) {
+                        const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + jj);
+                        resid[ft][tt][jj] = rv.x; resid[ft][tt][jj + 1] = rv.y; resid[ft][tt][jj + 2] = rv.z; resid[ft][tt][jj + 3] = rv.w;
+                    }
+                }
+            PIN();
         }
+        kstep(0, 2 * j, j, false);
+        kstep(1, 2 * j + 1, j, true);
     }
 
+    stamp(4);
     // ---- epilogue: + b3, + residual, fp32 row and SH8 copy --------------------------------------------------------------
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> inline-asm permlane reads
 #pragma unroll
@@ -366,9 +453,6 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
         const int fb = wf3 * 64 + ft * 32 + 16 * h;  // first of this lane's 16 consecutive output features
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
-            const int tok = m0 + wt3 * 64 + tt * 32 + i32;
-            const bool tok_ok = tok < p.T;
-            const long long tokc = tok_ok ? tok : 0;
             f32x16 w;
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -378,12 +462,11 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
                 w[e] = a0; w[4 + e] = b0; w[8 + e] = a1; w[12 + e] = b1;
             }
             const float* bp = s_par + 3 * HID + fb;
-            const float* rs = p.X + tokc * DOUT + fb;
 #pragma unroll
             for (int j = 0; j < 16; j += 4) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + j);
-                const f32x4 rv = *reinterpret_cast<const f32x4*>(rs + j);
-                w[j] = (w[j] + bv.x) + rv.x; w[j + 1] = (w[j + 1] + bv.y) + rv.y; w[j + 2] = (w[j + 2] + bv.z) + rv.z; w[j + 3] = (w[j + 3] + bv.w) + rv.w;
+                w[j] = (w[j] + bv.x) + resid[ft][tt][j]; w[j + 1] = (w[j + 1] + bv.y) + resid[ft][tt][j + 1];
+                w[j + 2] = (w[j + 2] + bv.z) + resid[ft][tt][j + 2]; w[j + 3] = (w[j + 3] + bv.w) + resid[ft][tt][j + 3];
             }
             const int ql = i32 & 3;
             const int tq = m0 + wt3 * 64 + tt * 32 + (i32 & ~3);  // first token of this lane's quad
@@ -413,12 +496,17 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
             }
         }
     }
+    if constexpr (STAMP) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(5);
+    }
 }
 
 }  // namespace
 
 void launch_ffn_f16x3(const FfnF16Args& a, hipStream_t s) {
     const dim3 grid((a.T + TMF - 1) / TMF);
-    if (a.act == 0) hipLaunchKernelGGL((ffn_f16x3_kernel<ACT_LN_GELU>), grid, dim3(FT), 0, s, a);
-    else hipLaunchKernelGGL((ffn_f16x3_kernel<ACT_RELU>), grid, dim3(FT), 0, s, a);
+    if (a.stamps) hipLaunchKernelGGL((ffn_f16x3_kernel<ACT_LN_GELU, true>), grid, dim3(FT), 0, s, a);
+    else if (a.act == 0) hipLaunchKernelGGL((ffn_f16x3_kernel<ACT_LN_GELU, false>), grid, dim3(FT), 0, s, a);
+    else hipLaunchKernelGGL((ffn_f16x3_kernel<ACT_RELU, false>), grid, dim3(FT), 0, s, a);
 }

@@ -129,6 +129,7 @@ struct FfnF16Args {
     int T = 0;
     float eps = 1e-5f;
     int act = 0;                 // 0: LayerNorm + GELU(erf) (LightGlue), 1: ReLU (SuperGlue / GlueStick, BatchNorm folded)
+    float* stamps = nullptr;     // diagnostic build only: 8 floats per workgroup (cycles since its start at the phase boundaries)
 };
 void launch_ffn_f16x3(const FfnF16Args& a, hipStream_t s);
 
