@@ -1448,6 +1448,25 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
 }
 
 // ------------------------------------------------------------------------------------------------
+int mg_wf_filter(mg_handle h, const float* keypoints, const float* scores, const float* descriptors, const int32_t* num_valid,
+                 const float* endpoints, int B, int K, int E, float radius, float* out_keypoints, float* out_scores, float* out_descriptors,
+                 int32_t* out_count, void* stream) {
+    if (!h || !keypoints || !scores || !descriptors || !out_keypoints || !out_scores || !out_descriptors || !out_count || (E > 0 && !endpoints))
+        return fail(MG_ERR_ARG, "NULL argument");
+    if (B < 1 || K < 1 || E < 0) return fail(MG_ERR_ARG, "bad shape");
+    HIPCHK(hipSetDevice(h->device));
+    WfFilterArgs a;
+    a.keypoints = keypoints; a.scores = scores; a.descriptors = descriptors; a.num_valid = num_valid; a.endpoints = endpoints;
+    a.B = B; a.K = K; a.E = E; a.radius = radius;
+    a.out_keypoints = out_keypoints; a.out_scores = out_scores; a.out_descriptors = out_descriptors; a.out_count = out_count;
+    a.src_row = reinterpret_cast<int*>(h->buf("wf.src", (size_t)B * K));
+    if (!a.src_row) return fail(MG_ERR_HIP, "workspace allocation failed");
+    launch_wf_filter(a, static_cast<hipStream_t>(stream));
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 int mg_nn_forward(mg_handle h, const mg_nn_conf* conf, const float* desc0, const float* desc1, int B, int M, int N, int D, int64_t* matches0,
                   int64_t* matches1, float* mscores0, float* mscores1, float* similarity, float* log_assignment, void* stream) {
     if (!h || !conf || !desc0 || !desc1 || !matches0 || !matches1 || !mscores0 || !mscores1) return fail(MG_ERR_ARG, "NULL argument");

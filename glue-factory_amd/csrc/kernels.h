@@ -158,6 +158,8 @@ struct SampleArgs {
     int B = 0, K = 0, hc = 0, wc = 0;
     int mode = 0;
     int normalize_cells = 0;           // 1: `dense` is NOT normalised yet; L2-normalise the four sampled cells on the fly
+    // mode 3 (MG_SAMPLE_CORNER): `keypoints` are raw pixel coordinates (no +0.5 to undo), grid = xy / (8 wc, 8 hc), align_corners=False
+    // = sample_descriptors_corner_conv, gluefactory/models/lines/wireframe.py:8-20 (junction descriptors)
     float* desc = nullptr;             // (B,K,256)
 };
 void launch_sample(const SampleArgs& a, hipStream_t s);
@@ -291,3 +293,20 @@ struct GsSoftmaxArgs {
 };
 void launch_gs_double_softmax(const GsSoftmaxArgs& a, hipStream_t s);
 void launch_gs_line_scores(const float* J, const long long* idx0, const long long* idx1, int B, int n0, int n1, float* raw, hipStream_t s);
+
+// ---- wf_misc.hip : wireframe side of GlueStick (keypoint / line-endpoint distance filter) --------
+struct WfFilterArgs {
+    const float* keypoints = nullptr;    // (B,K,2)
+    const float* scores = nullptr;       // (B,K)
+    const float* descriptors = nullptr;  // (B,K,256)
+    const int* num_valid = nullptr;      // optional (B): rows beyond it are padding already
+    const float* endpoints = nullptr;    // (B,E,2)
+    int B = 0, K = 0, E = 0;
+    float radius = 0.f;
+    float* out_keypoints = nullptr;      // (B,K,2) survivors first, original order, zero padding
+    float* out_scores = nullptr;         // (B,K)
+    float* out_descriptors = nullptr;    // (B,K,256)
+    int* out_count = nullptr;            // (B)
+    int* src_row = nullptr;              // (B,K) workspace: source row of every output row (-1: padding)
+};
+void launch_wf_filter(const WfFilterArgs& a, hipStream_t s);

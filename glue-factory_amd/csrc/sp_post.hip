@@ -313,12 +313,13 @@ __global__ __launch_bounds__(256) void sample_kernel(const SampleArgs p, float d
     const long long kp = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (kp >= (long long)p.B * p.K) return;
     const int b = (int)(kp / p.K);
-    const float xi = p.keypoints[kp * 2] - 0.5f, yi = p.keypoints[kp * 2 + 1] - 0.5f;
+    const float sh = p.mode == 3 ? 0.f : 0.5f;  // MG_SAMPLE_CORNER takes raw coordinates
+    const float xi = p.keypoints[kp * 2] - sh, yi = p.keypoints[kp * 2 + 1] - sh;
     float gx, gy, ix, iy;
     if (p.mode == 0) {  // legacy: shifted grid, align_corners=True
         gx = __fadd_rn(__fsub_rn(xi, 4.f), 0.5f);
         gy = __fadd_rn(__fsub_rn(yi, 4.f), 0.5f);
-    } else if (p.mode == 1) {
+    } else if (p.mode == 1 || p.mode == 3) {
         gx = xi; gy = yi;
     } else {
         gx = __fadd_rn(xi, 0.5f); gy = __fadd_rn(yi, 0.5f);

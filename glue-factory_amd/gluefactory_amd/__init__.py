@@ -8,6 +8,7 @@ Module paths usable as `model.extractor.name` / `model.matcher.name` in a glue-f
     gluefactory_amd.lightglue         LightGlue matcher             (models/matchers/lightglue.py)
     gluefactory_amd.superglue         SuperGlue matcher             (gluefactory_nonfree/superglue.py)
     gluefactory_amd.gluestick         GlueStick point+line matcher  (models/matchers/gluestick.py)
+    gluefactory_amd.wireframe         points + segments -> wireframe (models/lines/wireframe.py)
     gluefactory_amd.nearest_neighbor_matcher  mutual NN matcher     (models/matchers/nearest_neighbor_matcher.py)
     gluefactory_amd.two_view_pipeline extractor x2 -> matcher       (models/two_view_pipeline.py)
 

@@ -15,12 +15,12 @@ _PKG = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MG_LIB_PATH") or os.path.join(os.path.dirname(_PKG), "lib", "libmatchglue.so")
 
 MG_SP_MAGICLEAP, MG_SP_OPEN = 0, 1
-MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN = 0, 1, 2
+MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN, MG_SAMPLE_CORNER = 0, 1, 2, 3
 
 # every symbol include/matchglue.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_precision", "mg_set_weight", "mg_weights_ready",
-    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_sg_forward", "mg_gs_forward", "mg_nn_forward", "mg_debug_request", "mg_debug_read",
+    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_sg_forward", "mg_gs_forward", "mg_wf_filter", "mg_nn_forward", "mg_debug_request", "mg_debug_read",
     "mg_profile_enable", "mg_profile_read", "mg_test_linear", "mg_test_attention",
 ]
 
@@ -80,6 +80,7 @@ def lib():
     L.mg_lg_forward.argtypes = [c_void_p, POINTER(LgConf)] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 8
     L.mg_sg_forward.argtypes = [c_void_p, POINTER(SgConf)] + [c_void_p] * 8 + [c_int] * 3 + [c_void_p] * 7
     L.mg_gs_forward.argtypes = [c_void_p, POINTER(GsConf)] + [c_void_p] * 14 + [c_int] * 5 + [c_void_p] * 12
+    L.mg_wf_filter.argtypes = [c_void_p] + [c_void_p] * 5 + [c_int] * 3 + [c_float] + [c_void_p] * 5
     L.mg_nn_forward.argtypes = [c_void_p, POINTER(NnConf), c_void_p, c_void_p] + [c_int] * 4 + [c_void_p] * 7
     L.mg_debug_request.argtypes = [c_void_p, c_char_p]
     L.mg_debug_read.argtypes = [c_void_p, c_char_p, c_void_p, c_size_t, POINTER(c_size_t), c_void_p]
@@ -271,6 +272,22 @@ class Engine:
                                    _ptr(L0), _ptr(L1), _ptr(I0), _ptr(I1), _ptr(S0), _ptr(S1), B, M, N, n0, n1, _ptr(m0), _ptr(m1), _ptr(ms0),
                                    _ptr(ms1), _ptr(la), _ptr(lm0), _ptr(lm1), _ptr(lms0), _ptr(lms1), _ptr(lla), _ptr(raw), _stream(dev)))
         return (m0, m1, ms0, ms1, la), (lm0, lm1, lms0, lms1, lla, raw)
+
+    # -- wireframe ------------------------------------------------------------------------------------
+    def wf_filter(self, keypoints, scores, descriptors, endpoints, radius, num_valid=None):
+        """Drop the keypoints closer than `radius` to a line endpoint (wireframe.py:184-216); survivors first, original order."""
+        dev = self.device
+        kp, sc, ds, ep = (_f32(t, dev) for t in (keypoints, scores, descriptors, endpoints))
+        B, K, _ = kp.shape
+        E = ep.shape[1]
+        if sc.shape != (B, K) or ds.shape != (B, K, 256) or ep.shape != (B, E, 2):
+            raise RuntimeError("keypoints (B,K,2), scores (B,K), descriptors (B,K,256), endpoints (B,E,2) expected")
+        nv = None if num_valid is None else num_valid.to(device=dev, dtype=torch.int32).contiguous()
+        okp, osc, ods = torch.empty_like(kp), torch.empty_like(sc), torch.empty_like(ds)
+        cnt = torch.empty(B, dtype=torch.int32, device=dev)
+        _check(lib().mg_wf_filter(self._h, _ptr(kp), _ptr(sc), _ptr(ds), _ptr(nv), _ptr(ep), B, K, E, float(radius), _ptr(okp), _ptr(osc),
+                                  _ptr(ods), _ptr(cnt), _stream(dev)))
+        return okp, osc, ods, cnt
 
     # -- nearest-neighbour matcher ----------------------------------------------------------------
     def nn_forward(self, conf, d0, d1, want_similarity=True, want_log_assignment=True):

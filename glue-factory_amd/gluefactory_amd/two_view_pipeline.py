@@ -22,6 +22,8 @@ _ALIASES = {
     "matchers.gluestick": "gluefactory_amd.gluestick",
     "gluefactory.models.matchers.gluestick": "gluefactory_amd.gluestick",
     "gluefactory.models.matchers.nearest_neighbor_matcher": "gluefactory_amd.nearest_neighbor_matcher",
+    "lines.wireframe": "gluefactory_amd.wireframe",
+    "gluefactory.models.lines.wireframe": "gluefactory_amd.wireframe",
 }
 
 

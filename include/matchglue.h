@@ -40,7 +40,8 @@ enum mg_status {
 enum mg_sp_variant { MG_SP_MAGICLEAP = 0, MG_SP_OPEN = 1 };
 /* descriptor sampling conventions: superpoint.py:117-133 (legacy), :138-149 (fixed),
  * superpoint_open.py:20-31 (open) */
-enum mg_sampling { MG_SAMPLE_LEGACY = 0, MG_SAMPLE_FIXED = 1, MG_SAMPLE_OPEN = 2 };
+enum mg_sampling { MG_SAMPLE_LEGACY = 0, MG_SAMPLE_FIXED = 1, MG_SAMPLE_OPEN = 2,
+                   MG_SAMPLE_CORNER = 3 /* raw pixel coordinates: sample_descriptors_corner_conv, models/lines/wireframe.py:8-20 */ };
 
 /* Extractor configuration == the conf keys of superpoint.py:153-169 that the sparse path reads. */
 typedef struct mg_sp_conf {
@@ -64,7 +65,7 @@ int mg_create(int device, mg_handle* out);
 int mg_destroy(mg_handle h);
 const char* mg_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
-#define MG_ABI_VERSION 6 /* bumped whenever an entry point or a conf struct changes */
+#define MG_ABI_VERSION 7 /* bumped whenever an entry point or a conf struct changes */
 int mg_abi_version(void);   /* == MG_ABI_VERSION of the header the library was built from */
 
 /* -- arithmetic ------------------------------------------------------------------------------
@@ -160,6 +161,17 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
                   int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment,
                   int64_t* line_matches0, int64_t* line_matches1, float* line_mscores0, float* line_mscores1,
                   float* line_log_assignment, float* raw_line_scores, void* stream);
+
+/* -- wireframe side of GlueStick -------------------------------------------------
+ * gluefactory/models/lines/wireframe.py:184-216: keypoints closer than `radius` (torch.norm < r) to any line endpoint of
+ * their image are dropped; the survivors are compacted to the front in their original order, rows past out_count[b] are
+ * zero.  keypoints (B,K,2), scores (B,K), descriptors (B,K,256), endpoints (B,E,2) = lines.reshape(B,-1,2); num_valid
+ * optional (B): rows beyond it are padding already.  Outputs are separate buffers of the same shapes.
+ * Junction descriptors (wireframe.py:8-20,118) are mg_sp_sample with sampling = MG_SAMPLE_CORNER on the junction
+ * coordinates; line detection (LSD) and the DBSCAN merge of endpoints stay on the CPU, as in the reference. */
+int mg_wf_filter(mg_handle h, const float* keypoints, const float* scores, const float* descriptors,
+                 const int32_t* num_valid, const float* endpoints, int B, int K, int E, float radius,
+                 float* out_keypoints, float* out_scores, float* out_descriptors, int32_t* out_count, void* stream);
 
 /* -- nearest-neighbour matcher ------------------------------------------------
  * gluefactory/models/matchers/nearest_neighbor_matcher.py:51-72: sim = desc0 . desc1^T, best (and second best for

@@ -776,10 +776,75 @@ def gluestick_forward(data, W, **conf):
             "line_matching_scores1": ls1, "raw_line_scores": raw, "_taps": taps}
 
 
-def make_gs_weights(seed=0, n_layers=18, final_gain=6.0, bin_score=1.0, line_bin_score=0.5):
-    """Seeded GlueStick weights under the reference's state_dict key names (gluestick.py:62-100, 459-470, 561-700)."""
+# --------------------------------------------------------------------------
+# Wireframe extractor (the side feeding GlueStick)
+# --------------------------------------------------------------------------
+def corner_sample(points, dense, s=8):
+    """wireframe.py:8-20 `sample_descriptors_corner_conv`: bilinear sample of the dense map at raw pixel coordinates
+    (align_corners=False), L2-normalised.  points (B,n,2), dense (B,C,h,w) -> (B,n,C)."""
+    b, c, h, w = dense.shape
+    g = points / (points.new_tensor([w, h]) * s) * 2 - 1
+    d = F.grid_sample(dense, g.view(b, 1, -1, 2), mode="bilinear", align_corners=False)
+    return F.normalize(d.reshape(b, c, -1), p=2, dim=1).transpose(1, 2)
+
+
+def wireframe_forward(sp_pred, lines, line_scores, nms_radius=3, merge_points=True, merge_line_endpoints=True):
+    """wireframe.py:163-306 for one image (batch 1, no forced padding): `sp_pred` holds the point extractor's
+    `keypoints`, `keypoint_scores`, `descriptors`, `dense_descriptors`; lines (1,n,2,2), line_scores (1,n)."""
+    from sklearn.cluster import DBSCAN  # the reference's own CPU dependency for this step (wireframe.py:2,58)
+
+    kp, sc, ds, dense = sp_pred["keypoints"], sp_pred["keypoint_scores"], sp_pred["descriptors"], sp_pred["dense_descriptors"]
+    out = {"lines": lines, "line_scores": line_scores}
+    n_lines = lines.shape[1]
+    if n_lines:
+        out["line_scores"] = line_scores / (line_scores.max(dim=1)[0][:, None] + 1e-8)
+    if merge_points:  # :184-216
+        ends = lines.reshape(1, -1, 2)
+        dist = torch.norm(kp[:, :, None] - ends[:, None], dim=-1)
+        rm = torch.any(dist < nms_radius, dim=2)[0]
+        kp, sc, ds = kp[0][~rm][None], sc[0][~rm][None], ds[0][~rm][None]
+    orig = lines.clone()
+    if merge_line_endpoints and n_lines:  # :222-268 with lines_to_wireframe (:23-127)
+        ends = lines[0].reshape(-1, 2)
+        labels = torch.tensor(DBSCAN(eps=nms_radius, min_samples=1).fit(ends.numpy()).labels_, dtype=torch.long)
+        n = len(set(labels.tolist()))
+        junc = torch.zeros(n, 2).scatter_reduce_(0, labels[:, None].repeat(1, 2), ends, reduce="mean", include_self=False)
+        jsc = torch.zeros(n).scatter_reduce_(0, labels, torch.repeat_interleave(out["line_scores"][0], 2), reduce="mean", include_self=False)
+        out["lines"] = junc[labels].reshape(1, -1, 2, 2)
+        idx = labels.reshape(1, -1, 2)
+        jd = corner_sample(junc[None], dense)
+        pts, scores, descs = torch.cat([junc[None], kp], 1), torch.cat([jsc[None], sc], 1), torch.cat([jd, ds], 1)
+        assoc = torch.eye(pts.shape[1], dtype=torch.bool)
+        assoc[idx[0][:, 0], idx[0][:, 1]] = True
+        assoc[idx[0][:, 1], idx[0][:, 0]] = True
+        nj = n
+    else:  # :269-296
+        ends = lines.reshape(1, -1, 2)
+        pts = torch.cat([ends, kp], 1)
+        scores = torch.cat([torch.repeat_interleave(out["line_scores"], 2, dim=1), sc], 1)
+        descs = torch.cat([corner_sample(ends, dense), ds], 1)
+        assoc = torch.eye(pts.shape[1], dtype=torch.bool)
+        idx = torch.arange(n_lines * 2).reshape(1, -1, 2)
+        nj = n_lines * 2
+    out.update(keypoints=pts, keypoint_scores=scores, descriptors=descs, pl_associativity=assoc[None], num_junctions=torch.tensor([nj]),
+               orig_lines=orig, lines_junc_idx=idx)
+    return out
+
+
+# the weight set of tests/golden/gluestick.npz: points and lines of the synthetic pairs really match (see make_gs_weights)
+GS_GOLDEN = dict(structured=True, final_gain=10.0, bin_score=0.0, line_bin_score=0.0)
+
+
+def make_gs_weights(seed=0, n_layers=18, final_gain=6.0, bin_score=1.0, line_bin_score=0.5, structured=False):
+    """Seeded GlueStick weights under the reference's state_dict key names (gluestick.py:62-100, 459-470, 561-700).
+
+    `structured=True` keeps the residual stream close to the input descriptors (small gains on everything that is
+    ADDED to it: the last encoder layer, `mlp.3` of the GNN and line layers) so that corresponding points and lines of
+    the synthetic pairs really match -- the plain random set matches 1-2 % of them, which makes an "agreement" figure
+    mostly agreement on -1."""
     g = torch.Generator().manual_seed(seed)
     W = {}
+    add_gain = 0.02 if structured else 0.3
 
     def conv(name, co, ci, gain=1.0, zero_bias=False):
         W[name + ".weight"] = torch.randn(co, ci, 1, generator=g) * gain / math.sqrt(ci)
@@ -796,7 +861,7 @@ def make_gs_weights(seed=0, n_layers=18, final_gain=6.0, bin_score=1.0, line_bin
         chans = [cin, 32, 64, 128, 256, 256]
         idx = 0
         for i in range(5):
-            conv(f"{enc}.encoder.{idx}", chans[i + 1], chans[i], gain=0.3 if i == 4 else 1.4, zero_bias=(i == 4))
+            conv(f"{enc}.encoder.{idx}", chans[i + 1], chans[i], gain=add_gain if i == 4 else 1.4, zero_bias=(i == 4))
             idx += 1
             if i < 4:
                 bn(f"{enc}.encoder.{idx}", chans[i + 1])
@@ -808,12 +873,12 @@ def make_gs_weights(seed=0, n_layers=18, final_gain=6.0, bin_score=1.0, line_bin
             conv(p + f".attn.proj.{j}", 256, 256, gain=1.0)
         conv(p + ".mlp.0", 512, 512, gain=1.4)
         bn(p + ".mlp.1", 512)
-        conv(p + ".mlp.3", 256, 512, gain=0.3, zero_bias=True)
+        conv(p + ".mlp.3", 256, 512, gain=add_gain, zero_bias=True)
     for l in range(n_layers // 2):
         p = f"gnn.line_layers.{l}"
         conv(p + ".mlp.0", 512, 768, gain=1.4)
         bn(p + ".mlp.1", 512)
-        conv(p + ".mlp.3", 256, 512, gain=0.3, zero_bias=True)
+        conv(p + ".mlp.3", 256, 512, gain=add_gain, zero_bias=True)
     eye = torch.eye(256)[:, :, None]
     W["final_proj.weight"] = final_gain * eye + 0.05 * torch.randn(256, 256, 1, generator=g)
     W["final_proj.bias"] = torch.zeros(256)

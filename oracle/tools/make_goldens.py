@@ -266,38 +266,16 @@ def gold_superglue():
 
 
 # ---------------------------------------------------------------- (5) two-view pipeline on the boat pair
-def gs_inputs(B, M, N, n0, n1, seed, share=0.6):
-    """Synthetic wireframe-style inputs: the first junctions of the keypoint list are line endpoints
-    (`lines_junc_idx` < 2 * n_lines, several endpoints share a junction), image 1 is a noisy re-ordering of image 0."""
-    g = torch.Generator().manual_seed(300 + seed)
-    size0 = torch.tensor([[640.0, 480.0]] * B)
-    size1 = torch.tensor([[600.0, 480.0]] * B)
-    K = max(M, N)
-    kk = torch.rand(B, K, 2, generator=g) * size1[:, None] * 0.98 + 0.5
-    dd = torch.nn.functional.normalize(torch.randn(B, K, 256, generator=g), dim=-1)
-    k0, d0 = kk[:, :M].contiguous(), dd[:, :M].contiguous()
-    perm = torch.stack([torch.randperm(K, generator=g)[:N] for _ in range(B)])
-    k1 = (torch.gather(kk, 1, perm[..., None].expand(-1, -1, 2)) * 0.9 + 3.0 * torch.randn(B, N, 2, generator=g)).clamp(1.0, 479.0)
-    d1 = torch.nn.functional.normalize(torch.gather(dd, 1, perm[..., None].expand(-1, -1, 256)) + 0.05 * torch.randn(B, N, 256, generator=g), dim=-1)
-    out = {"keypoints0": k0, "keypoints1": k1, "descriptors0": d0, "descriptors1": d1,
-           "keypoint_scores0": torch.rand(B, M, generator=g), "keypoint_scores1": torch.rand(B, N, generator=g),
-           "view0": {"image_size": size0}, "view1": {"image_size": size1}}
-    for side, n, kp in (("0", n0, k0), ("1", n1, k1)):
-        J = max(2, int(2 * n * share))  # junctions actually used (< 2n: endpoints share junctions)
-        idx = torch.randint(0, J, (B, n, 2), generator=g)
-        idx[:, :, 1] = torch.where(idx[:, :, 1] == idx[:, :, 0], (idx[:, :, 1] + 1) % J, idx[:, :, 1])
-        out["lines_junc_idx" + side] = idx
-        out["lines" + side] = torch.gather(kp, 1, idx.reshape(B, 2 * n)[..., None].expand(-1, -1, 2)).reshape(B, n, 2, 2)
-        out["line_scores" + side] = torch.rand(B, n, generator=g)
-    return out
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from gs_inputs import gs_inputs  # noqa: E402  (the synthetic wireframe-style pair generator, shared with the tests)
 
 
 def gold_gluestick():
     Ref = get_model("matchers.gluestick")
     arrs = {}
     for tag, B, M, N, n0, n1, seed in (("a", 2, 48, 40, 10, 8, 1), ("b", 1, 64, 64, 16, 16, 2), ("c", 2, 33, 70, 5, 12, 3)):
-        W = O.make_gs_weights(seed)
-        data = gs_inputs(B, M, N, n0, n1, seed)
+        W = O.make_gs_weights(seed, **O.GS_GOLDEN)
+        data = gs_inputs(B, M, N, n0, n1, seed, corresponding=True)
         for k, v in data.items():
             if k.startswith("view"):
                 arrs[f"{tag}.size{k[-1]}"] = v["image_size"]
@@ -314,8 +292,55 @@ def gold_gluestick():
             if th == 0.0:
                 for k in ("log_assignment", "line_log_assignment", "raw_line_scores"):
                     arrs[f"{tag}.{k}"] = p[k]
-        print("gluestick", tag, "matches", int((p["matches0"] > -1).sum()), "of", B * M, "line matches", int((p["line_matches0"] > -1).sum()), "of", B * n0)
+        print("gluestick", tag, "matches", int((p["matches0"] > -1).sum()), "of", B * M, f"(possible {B * min(M, N)})", "line matches",
+              int((p["line_matches0"] > -1).sum()), "of", B * n0, f"(possible {B * min(n0, n1)})")
     save("gluestick", **arrs)
+
+
+def wireframe_segments(kp, n, seed, w, h):
+    """Synthetic segments for the wireframe fixture (LSD is a CPU dependency and not part of the path): endpoints near
+    detected keypoints (so the distance filter has something to remove), endpoints shared or 1-2 px apart between
+    segments (so DBSCAN merges them), and free ones.  No keypoint-endpoint distance falls within 1e-3 of the radius."""
+    g = torch.Generator().manual_seed(seed)
+    ends = torch.rand(n, 2, 2, generator=g) * torch.tensor([w - 9.0, h - 9.0]) + 4.0
+    k = kp[torch.randperm(len(kp), generator=g)[: n // 2]]
+    ends[: n // 2, 0] = k + (torch.rand(n // 2, 2, generator=g) - 0.5) * 3.0      # within ~2 px of a keypoint
+    ends[1: n // 3, 1] = ends[: n // 3 - 1, 0] + (torch.rand(n // 3 - 1, 2, generator=g) - 0.5) * 2.0  # chains: next segment starts where one ends
+    ends[n // 2, 0] = ends[0, 1]                                                    # an exactly shared endpoint
+    return ends[None].contiguous(), (torch.rand(1, n, generator=g) * 5 + 0.1)
+
+
+def gold_wireframe(boat):
+    """gluefactory/models/lines/wireframe.py run as is on fixed extractor outputs: `WireframeExtractor._forward` (and through it
+    `lines_to_wireframe`, `sample_descriptors_corner_conv`) with its two sub-extractors replaced by callables that return the
+    SuperPoint outputs of a boat crop and synthetic segments -- everything downstream of the extractors is the reference's code."""
+    from omegaconf import OmegaConf
+
+    from gluefactory.models.lines import wireframe as ref_wf
+
+    gray = torch.from_numpy(np.asarray(boat[0]).astype(np.float32) @ np.array([0.299, 0.587, 0.114], np.float32)) / 255.0
+    img = gray[200:320, 300:460][None, None].contiguous()
+    sp = O.superpoint_forward({"image": img}, O.make_sp_weights(0), nms_radius=3, detection_threshold=0.0, max_num_keypoints=96)
+    sp_pred = {k: sp[k] for k in ("keypoints", "keypoint_scores", "descriptors", "dense_descriptors")}
+    arrs = {"image": img, **{"sp." + k: v for k, v in sp_pred.items()}}
+    for tag, n, merge_ends in (("merge", 24, True), ("plain", 10, False), ("nolines", 0, True)):
+        lines, scores = wireframe_segments(sp_pred["keypoints"][0], max(n, 8), 7 + n, 160, 120)
+        lines, scores = lines[:, :n], scores[:, :n]
+        d = torch.norm(sp_pred["keypoints"][:, :, None] - lines.reshape(1, -1, 2)[:, None], dim=-1)
+        assert not bool(((d - 3.0).abs() < 1e-3).any()), "a keypoint sits on the filter radius: re-seed the fixture"
+        ext = object.__new__(ref_wf.WireframeExtractor)
+        torch.nn.Module.__init__(ext)
+        ext.conf = OmegaConf.create({"point_extractor": {"force_num_keypoints": False}, "line_extractor": {"force_num_lines": False, "max_num_lines": None},
+                                     "wireframe_params": {"merge_points": True, "merge_line_endpoints": merge_ends, "nms_radius": 3}})
+        ext.point_extractor = lambda data: {k: v.clone() for k, v in sp_pred.items()}
+        ext.line_extractor = lambda data: {"lines": lines.clone(), "line_scores": scores.clone()}
+        out = ext._forward({"image": img})
+        arrs[tag + ".in.lines"], arrs[tag + ".in.line_scores"] = lines, scores
+        for k, v in out.items():
+            arrs[f"{tag}.{k}"] = v.to(torch.uint8) if v.dtype == torch.bool else v
+        print("wireframe", tag, "keypoints kept", out["keypoints"].shape[1] - int(out["num_junctions"][0]), "of", sp_pred["keypoints"].shape[1],
+              "junctions", int(out["num_junctions"][0]), "of", 2 * n, "endpoints")
+    save("wireframe", **arrs)
 
 
 def export_fixture(n_pairs=4, K=12, seed=41):
@@ -441,4 +466,5 @@ if __name__ == "__main__":
     gold_nn()
     gold_export()
     gold_gluestick()
+    gold_wireframe(boat)
     gold_two_view(boat)

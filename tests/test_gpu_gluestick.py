@@ -44,7 +44,7 @@ def _data(g, tag):
 def test_gluestick_golden(dev, golden, precision):
     g = golden("gluestick")
     for tag, seed in (("a", 1), ("b", 2), ("c", 3)):
-        W = O.make_gs_weights(seed)
+        W = O.make_gs_weights(seed, **O.GS_GOLDEN)
         data = _data(g, tag)
         ref = O.gluestick_forward(data, W, filter_threshold=0.0)
         B, M = data["keypoints0"].shape[:2]
@@ -79,8 +79,8 @@ def test_gluestick_vs_oracle_large(dev, precision):
     mod = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mod)
     B, M, N, n0, n1 = 2, 1000, 1100, 250, 230
-    data = mod.gs_inputs(B, M, N, n0, n1, 7)
-    W = O.make_gs_weights(4)
+    data = mod.gs_inputs(B, M, N, n0, n1, 7, corresponding=True)  # lines of image 1 are the counterparts of image 0's: matches exist
+    W = O.make_gs_weights(4, **O.GS_GOLDEN)
     ref = O.gluestick_forward(data, W, filter_threshold=0.2)
     p = _module(W, 0.2, precision)(_to(data, dev))
     for k in ("log_assignment", "line_log_assignment", "raw_line_scores"):

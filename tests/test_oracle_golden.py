@@ -195,7 +195,7 @@ def test_gluestick_matches_reference(golden):
     """gluefactory/models/matchers/gluestick.py run by oracle/tools/make_goldens.py."""
     g = golden("gluestick")
     for tag, seed in (("a", 1), ("b", 2), ("c", 3)):
-        W = O.make_gs_weights(seed)
+        W = O.make_gs_weights(seed, **O.GS_GOLDEN)
         for th in (0.0, 0.2):
             p = O.gluestick_forward(_gs_data(g, tag), W, filter_threshold=th)
             for k in GS_INT:
@@ -204,3 +204,26 @@ def test_gluestick_matches_reference(golden):
                 torch.testing.assert_close(p[k], g[f"{tag}.th{th}.{k}"], rtol=0, atol=1e-5)
         for k in ("log_assignment", "line_log_assignment", "raw_line_scores"):
             torch.testing.assert_close(p[k], g[f"{tag}.{k}"], rtol=1e-5, atol=1e-4)
+
+
+WF_KEYS = ("keypoints", "keypoint_scores", "descriptors", "lines", "line_scores", "orig_lines", "lines_junc_idx", "num_junctions", "pl_associativity")
+
+
+def test_wireframe_matches_reference(golden):
+    """SURVEY 8f rank 3, wireframe side: gluefactory/models/lines/wireframe.py (`WireframeExtractor._forward`,
+    `lines_to_wireframe`, `sample_descriptors_corner_conv`) run by oracle/tools/make_goldens.py on fixed extractor outputs."""
+    g = golden("wireframe")
+    sp = {k: g["sp." + k] for k in ("keypoints", "keypoint_scores", "descriptors", "dense_descriptors")}
+    for tag, merge_ends in (("merge", True), ("plain", False), ("nolines", True)):
+        p = O.wireframe_forward(sp, g[tag + ".in.lines"], g[tag + ".in.line_scores"], nms_radius=3, merge_line_endpoints=merge_ends)
+        for k in WF_KEYS:
+            want = g[f"{tag}.{k}"]
+            got = p[k].to(torch.uint8) if p[k].dtype == torch.bool else p[k]
+            assert got.shape == want.shape, (tag, k, got.shape, want.shape)
+            if got.dtype.is_floating_point:
+                torch.testing.assert_close(got, want, rtol=0, atol=1e-6, msg=lambda s: f"{tag} {k}: {s}")
+            else:
+                assert torch.equal(got, want), (tag, k)
+    # the fixture exercises both GPU steps: keypoints are removed, endpoints are merged
+    assert g["merge.keypoints"].shape[1] - int(g["merge.num_junctions"][0]) < sp["keypoints"].shape[1]
+    assert int(g["merge.num_junctions"][0]) < 2 * g["merge.in.lines"].shape[1]
