@@ -29,7 +29,10 @@ class Group(dict):
 class File(Group):
     def __init__(self, path, mode="r"):
         super().__init__()
-        FILES[str(path)] = self
+        if mode == "r":  # re-open what an earlier File(path, "w") recorded (CacheLoader reads it back)
+            self.update(FILES[str(path)])
+        else:
+            FILES[str(path)] = self
 
     def close(self):
         pass

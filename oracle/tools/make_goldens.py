@@ -384,6 +384,29 @@ def gold_export():
         for name, grp in h5py.FILES[out].items():
             for k, ds in grp.items():
                 arrs[f"half{int(half)}|{name}|{k}"] = ds.data
+        # Round trip through the consumer: THIS build's batched exporter (zero-padded batches of 3) writes the fixture, the
+        # reference's own CacheLoader (models/cache_loader.py:59-141) reads both files back; what it returns must be the same
+        # tensors, and is kept as the fixture of the read-back test.
+        sys.path.insert(0, os.path.join(ROOT, "glue-factory_amd"))
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        from test_export_h5 import _batched_loader, _model
+
+        from gluefactory.models.cache_loader import CacheLoader
+        from gluefactory_amd.export import export_predictions as export_batched
+
+        ours = f"/tmp/export_ours_{int(half)}.h5"
+        export_batched(_batched_loader(pairs, 3), _model, ours, as_half=half, h5=h5py)
+        for i, (name, _, s0, s1) in enumerate(pairs):
+            data = {"name": [name], "view0": {"scales": s0[None]}, "view1": {"scales": s1[None]}}
+            got = {}
+            for path in (out, ours):
+                cl = CacheLoader({"path": path, "add_data_path": False, "collate": False})
+                got[path] = cl(data)
+            assert sorted(got[out]) == sorted(got[ours]), (name, sorted(got[out]), sorted(got[ours]))
+            for k in got[out]:
+                assert got[out][k].dtype == got[ours][k].dtype and torch.equal(got[out][k], got[ours][k]), (name, k)
+                arrs[f"cache{int(half)}|{name}|{k}"] = got[ours][k]
+        print(f"export (half={half}): the reference CacheLoader reads {len(pairs)} pairs x {len(got[ours])} keys identically from the reference's and from the batched export")
     save("export_h5", **arrs)
 
 
