@@ -4,6 +4,7 @@
 
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -110,6 +111,11 @@ struct mg_context {
     LinLayer final_proj;
     float* match_w = nullptr;
     float match_b = 0.f;
+    // adaptive depth / width: the assignment head and the token-confidence head of EVERY layer (prepared on first adaptive use)
+    int lg_heads = -1;
+    std::vector<LinLayer> lg_final;
+    std::vector<float*> lg_match_w, lg_tok_w;
+    std::vector<float> lg_match_b, lg_tok_b;
     float* Wr = nullptr;
     // SuperGlue
     int sg_layers = -1;
@@ -412,6 +418,7 @@ int prep_ffn(mg_context* h, const std::string& p, LgBlock* blk) {
 int prepare_lg(mg_context* h, int n_layers) {
     if (h->lg_layers == n_layers) return 0;
     h->lg_layers = -1;
+    h->lg_heads = -1;
     if (int rc = begin_prepare(h, 1)) return rc;
     h->lg_self.assign(n_layers, LgBlock());
     h->lg_cross.assign(n_layers, LgBlock());
@@ -465,6 +472,38 @@ int prepare_lg(mg_context* h, int n_layers) {
     if (int rc = need(h, 1, "posenc.Wr.weight", {32, 2}, &wr)) return rc;
     if (int rc = upload(h, wr->data, &h->Wr)) return rc;
     h->lg_layers = n_layers;
+    return 0;
+}
+
+// heads used only by the adaptive path: log_assignment.{i} for every layer (the loop may stop at any of them, lightglue.py:495-496)
+// and token_confidence.{i} for i < n_layers - 1 (:352-354)
+int prepare_lg_heads(mg_context* h, int n_layers, bool need_tokens) {
+    if (int rc = prepare_lg(h, n_layers)) return rc;
+    if (h->lg_heads == n_layers + (need_tokens ? 1000 : 0)) return 0;
+    h->cur_which = 1;
+    h->lg_final.assign(n_layers, LinLayer());
+    h->lg_match_w.assign(n_layers, nullptr);
+    h->lg_match_b.assign(n_layers, 0.f);
+    h->lg_tok_w.assign(n_layers, nullptr);
+    h->lg_tok_b.assign(n_layers, 0.f);
+    for (int i = 0; i < n_layers; ++i) {
+        const std::string pa = "log_assignment." + std::to_string(i);
+        if (int rc = prep_linear(h, 1, pa + ".final_proj", 256, 256, &h->lg_final[i])) return rc;
+        const HostTensor *mw, *mb;
+        if (int rc = need(h, 1, pa + ".matchability.weight", {1, 256}, &mw)) return rc;
+        if (int rc = need(h, 1, pa + ".matchability.bias", {1}, &mb)) return rc;
+        if (int rc = upload(h, mw->data, &h->lg_match_w[i])) return rc;
+        h->lg_match_b[i] = mb->data[0];
+        if (need_tokens && i < n_layers - 1) {
+            const std::string pt = "token_confidence." + std::to_string(i) + ".token.0";
+            const HostTensor *tw, *tb;
+            if (int rc = need(h, 1, pt + ".weight", {1, 256}, &tw)) return rc;
+            if (int rc = need(h, 1, pt + ".bias", {1}, &tb)) return rc;
+            if (int rc = upload(h, tw->data, &h->lg_tok_w[i])) return rc;
+            h->lg_tok_b[i] = tb->data[0];
+        }
+    }
+    h->lg_heads = n_layers + (need_tokens ? 1000 : 0);
     return 0;
 }
 
@@ -944,44 +983,61 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
 }
 
 // ------------------------------------------------------------------------------------------------
-int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
+// The LightGlue forward; `ad` != nullptr selects the adaptive depth / width variant (batch 1).
+struct LgAdaptive {
+    float depth = -1.f, width = -1.f;
+    int32_t* prune0 = nullptr;  // (M) / (N) int32, device
+    int32_t* prune1 = nullptr;
+    int32_t* out_dims = nullptr;  // host: M', N', layers run
+};
+
+static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
                   const float* size0, const float* size1, int B, int M, int N, int64_t* matches0, int64_t* matches1, float* mscores0,
-                  float* mscores1, float* log_assignment, float* ref_desc0, float* ref_desc1, void* stream) {
+                  float* mscores1, float* log_assignment, float* ref_desc0, float* ref_desc1, void* stream, const LgAdaptive* ad) {
     if (!h || !conf || !kpts0 || !kpts1 || !desc0 || !desc1 || !matches0 || !matches1 || !mscores0 || !mscores1) return fail(MG_ERR_ARG, "NULL argument");
     if (B < 1 || M < 1 || N < 1) return fail(MG_ERR_ARG, "empty input");
     if (conf->num_heads != 4) return fail(MG_ERR_ARG, "num_heads must be 4 (descriptor_dim 256, head_dim 64)");
     if (conf->n_layers < 1) return fail(MG_ERR_ARG, "n_layers must be >= 1");
+    const bool do_stop = ad && ad->depth > 0.f, do_prune = ad && ad->width > 0.f;
+    if (ad && B != 1) return fail(MG_ERR_ARG, "adaptive depth / width needs batch 1 (lightglue.py:476,:481 assert it)");
     HIPCHK(hipSetDevice(h->device));
-    if (int rc = prepare_lg(h, conf->n_layers)) return rc;
+    if (ad) {
+        if (int rc = prepare_lg_heads(h, conf->n_layers, do_stop)) return rc;
+    } else if (int rc = prepare_lg(h, conf->n_layers)) {
+        return rc;
+    }
     hipStream_t s = static_cast<hipStream_t>(stream);
 
-    const size_t T0 = (size_t)B * M, T1 = (size_t)B * N, T = T0 + T1;
-    float* X = h->buf("lg.x", T * 256);
-    float* QKV = h->buf("lg.qkv", T * 768);
-    float* CTX = h->buf("lg.ctx", T * 256);
-    float* MSG = h->buf("lg.msg", T * 256);
-    float* HID = h->buf("lg.hid", T * 512);
-    float* ENC = h->buf("lg.enc", T * 64);
+    const size_t T0_in = (size_t)B * M, T1_in = (size_t)B * N, Tin = T0_in + T1_in;
+    float* X = h->buf("lg.x", Tin * 256);
+    float* QKV = h->buf("lg.qkv", Tin * 768);
+    float* CTX = h->buf("lg.ctx", Tin * 256);
+    float* MSG = h->buf("lg.msg", Tin * 256);
+    float* HID = h->buf("lg.hid", Tin * 512);
+    float* ENC = h->buf("lg.enc", Tin * 64);
     float* SIM = h->buf("lg.sim", (size_t)B * M * N);
-    float* Z = h->buf("lg.z", T);
-    float* ST = h->buf("lg.stats", 6 * T + 16);
+    float* Z = h->buf("lg.z", Tin);
+    float* ST = h->buf("lg.stats", 6 * Tin + 16);
     if (!X || !QKV || !CTX || !MSG || !HID || !ENC || !SIM || !Z || !ST) return fail(MG_ERR_HIP, "workspace allocation failed");
 
-    HIPCHK(hipMemcpyAsync(X, desc0, T0 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(X + T0 * 256, desc1, T1 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(X, desc0, T0_in * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(hipMemcpyAsync(X + T0_in * 256, desc1, T1_in * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
     {
         ProfScope ps(h, s, "lg.posenc");
         launch_posenc(kpts0, kpts1, size0, size1, h->Wr, B, M, N, ENC, s);
     }
-    if (int rc = tap_copy(h, "lg.enc", ENC, T * 64, s)) return rc;
+    if (int rc = tap_copy(h, "lg.enc", ENC, Tin * 64, s)) return rc;
 
     const bool f16 = h->precision == MG_PREC_F16X3;
     float* XS = nullptr;
     if (f16) {
-        XS = h->buf("lg.xs", T * 256);
+        XS = h->buf("lg.xs", Tin * 256);
         if (!XS) return fail(MG_ERR_HIP, "workspace allocation failed");
-        launch_to_sh8(X, XS, (long long)T * 256, 1.f, s);
+        launch_to_sh8(X, XS, (long long)Tin * 256, 1.f, s);
     }
+    // current token counts: only the adaptive variant changes them (point pruning)
+    int Mc = M, Nc = N;
+    size_t T0 = T0_in, T = Tin;
 
     // the three-launch form stays reachable for A/B timing (environment) and for the equivalence test (debug tap request)
     static const bool unfused_env = getenv("MG_FFN_UNFUSED") != nullptr;
@@ -1051,12 +1107,12 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         if (f16) {
             AttnF16Args a;
             a.q = QKV; a.k = QKV; a.v = QKV; a.ld = ld; a.q_col = 0; a.k_col = kcol; a.v_col = vcol;
-            a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+            a.out = CTX; a.ldo = 256; a.B = B; a.M = Mc; a.N = Nc; a.heads = 4; a.cross = cross;
             launch_attention_f16x3(a, s);
         } else {
             AttnArgs a;
             a.q = QKV; a.k = QKV; a.v = QKV; a.ld = ld; a.q_col = 0; a.k_col = kcol; a.v_col = vcol;
-            a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+            a.out = CTX; a.ldo = 256; a.B = B; a.M = Mc; a.N = Nc; a.heads = 4; a.cross = cross;
             launch_attention(a, s);
         }
     };
@@ -1069,6 +1125,21 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         }
     };
 
+    // adaptive state (batch 1): original index of every surviving token, pruning rounds survived, alternate buffers for the compaction
+    int32_t *IND = nullptr, *IND2 = nullptr, *CNT = nullptr;
+    float *X2 = nullptr, *XS2 = nullptr, *ENC2 = nullptr, *ZT = nullptr;
+    if (ad) {
+        IND = reinterpret_cast<int32_t*>(h->buf("lg.ind", Tin));
+        IND2 = reinterpret_cast<int32_t*>(h->buf("lg.ind2", Tin));
+        CNT = reinterpret_cast<int32_t*>(h->buf("lg.cnt", 8));
+        X2 = h->buf("lg.x2", Tin * 256);
+        XS2 = h->buf("lg.xs2", Tin * 256);
+        ENC2 = h->buf("lg.enc2", Tin * 64);
+        ZT = h->buf("lg.zt", Tin);
+        if (!IND || !IND2 || !CNT || !X2 || !XS2 || !ENC2 || !ZT) return fail(MG_ERR_HIP, "workspace allocation failed");
+        launch_lg_adaptive_init(IND, ad->prune0, ad->prune1, M, N, s);
+    }
+    int last = conf->n_layers - 1;  // the layer whose assignment head is used
     for (int i = 0; i < conf->n_layers; ++i) {
         const LgBlock& sb = h->lg_self[i];
         // f16x3: log2(e) is folded into the logit scale so the attention kernel uses bare v_exp_f32
@@ -1085,19 +1156,52 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         outproj(cb);
         ffn(cb);
         if (int rc = tap_copy(h, "lg.layer" + std::to_string(i), X, T * 256, s)) return rc;
+
+        if (!ad || i == conf->n_layers - 1) continue;  // no early stopping or adaptive width at the last layer (lightglue.py:469-472)
+        const float thr = (float)std::min(1.0, std::max(0.0, 0.8 + 0.1 * std::exp(-4.0 * i / conf->n_layers)));  // confidence_threshold(i), :536-539
+        if (do_stop) {  // :474-479 with :551-560; the pruned points count as confident (num_points stays m + n)
+            launch_matchability(X, (long long)T, h->lg_tok_w[i], h->lg_tok_b[i], ZT, s);
+            launch_lg_count_below(ZT, (int)T, thr, CNT + 2, s);
+            int32_t below = 0;
+            HIPCHK(hipMemcpyAsync(&below, CNT + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            const float ratio = 1.0f - (float)below / (float)(M + N);
+            if (ratio > ad->depth) { last = i; break; }
+        }
+        if (do_prune) {  // :480-497 with get_pruning_mask :541-549
+            launch_matchability(X, (long long)T, h->lg_match_w[i], h->lg_match_b[i], Z, s);
+            LgPruneArgs pa;
+            pa.z = Z; pa.zt = do_stop ? ZT : nullptr; pa.thr_tok = thr; pa.thr_keep = (float)(1.0 - (double)ad->width);
+            pa.M = Mc; pa.N = Nc; pa.ind = IND; pa.ind_out = IND2; pa.prune0 = ad->prune0; pa.prune1 = ad->prune1; pa.src = reinterpret_cast<int32_t*>(ST);
+            pa.counts = CNT;
+            pa.x = X; pa.xs = XS; pa.enc = ENC; pa.x_out = X2; pa.xs_out = XS2; pa.enc_out = ENC2;
+            launch_lg_prune(pa, s);
+            int32_t cnt[2] = {0, 0};
+            HIPCHK(hipMemcpyAsync(cnt, CNT, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            launch_lg_prune_gather(pa, cnt[0], cnt[1], s);
+            std::swap(X, X2); std::swap(XS, XS2); std::swap(ENC, ENC2); std::swap(IND, IND2);
+            Mc = cnt[0]; Nc = cnt[1];
+            T0 = (size_t)Mc; T = (size_t)Mc + Nc;
+            if (Mc < 1 || Nc < 1) return fail(MG_ERR_STATE, "point pruning removed every keypoint of an image");
+        }
     }
 
-    // assignment head (lightglue.py:265-303)
+    // assignment head (lightglue.py:265-303) of the last layer that ran
+    const LinLayer& fproj = ad ? h->lg_final[last] : h->final_proj;
+    const float* mw = ad ? h->lg_match_w[last] : h->match_w;
+    const float mbias = ad ? h->lg_match_b[last] : h->match_b;
+    const size_t T1 = T - T0;
     float* MD = QKV;  // reuse: (T,256) projected descriptors
     {
         ProfScope ps(h, s, "lg.gemm.final_proj");
         if (f16) {
-            GemmF16Args g = lin_args_f16(h->final_proj, XS, 256, (int)T);
+            GemmF16Args g = lin_args_f16(fproj, XS, 256, (int)T);
             g.Cs = MD; g.ldcs = 256;
             g.scale = 0.25f; g.scale_cols = 256;
             launch_gemm_f16x3(g, s);
         } else {
-            GemmArgs g = lin_args(h->final_proj, X, 256, (int)T, MD, 256);
+            GemmArgs g = lin_args(fproj, X, 256, (int)T, MD, 256);
             g.scale = 0.25f;  // / 256^(1/4)
             g.scale_cols = 256;
             launch_gemm(g, s);
@@ -1110,23 +1214,34 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
             GemmF16Args g;
             g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
             g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
-            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
+            g.C = SIM; g.ldc = Nc; g.M = Mc; g.N = Nc; g.K = 256;
+            g.batch = B; g.strideA = (long long)Mc * 256; g.strideW = (long long)Nc * 256; g.strideC = (long long)Mc * Nc;
             launch_gemm_f16x3(g, s);
         } else {
             GemmArgs g;
             g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
             g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = SIM; g.ldc = N; g.M = M; g.N = N; g.K = 256;
-            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)M * N;
+            g.C = SIM; g.ldc = Nc; g.M = Mc; g.N = Nc; g.K = 256;
+            g.batch = B; g.strideA = (long long)Mc * 256; g.strideW = (long long)Nc * 256; g.strideC = (long long)Mc * Nc;
             launch_gemm(g, s);
         }
     }
+    // the adaptive variant assigns in the surviving points' index space and scatters back to the original one afterwards
+    long long* am0 = reinterpret_cast<long long*>(matches0);
+    long long* am1 = reinterpret_cast<long long*>(matches1);
+    float *as0 = mscores0, *as1 = mscores1;
+    if (do_prune) {
+        am0 = reinterpret_cast<long long*>(h->buf("lg.am", 2 * (T + 2)));
+        as0 = h->buf("lg.as", T + 2);
+        if (!am0 || !as0) return fail(MG_ERR_HIP, "workspace allocation failed");
+        am1 = am0 + T0;
+        as1 = as0 + T0;
+    }
     {
         ProfScope ps(h, s, "lg.assign");
-        launch_matchability(X, (long long)T, h->match_w, h->match_b, Z, s);
+        launch_matchability(X, (long long)T, mw, mbias, Z, s);
         AssignArgs a;
-        a.sim = SIM; a.z0 = Z; a.z1 = Z + T0; a.B = B; a.M = M; a.N = N; a.threshold = conf->filter_threshold;
+        a.sim = SIM; a.z0 = Z; a.z1 = Z + T0; a.B = B; a.M = Mc; a.N = Nc; a.threshold = conf->filter_threshold;
         a.row_mx = ST; a.row_ls = ST + T0; a.row_best = ST + 2 * T0;
         a.row_arg = reinterpret_cast<int*>(ST + 3 * T0);
         float* cbase = ST + 4 * T0;
@@ -1134,14 +1249,36 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         a.col_arg = reinterpret_cast<int*>(cbase + 3 * T1);
         a.ls0 = ST + 4 * T; a.ls1 = a.ls0 + T0; a.lsn0 = ST + 5 * T; a.lsn1 = a.lsn0 + T0;
         a.log_assignment = log_assignment;
-        a.m0 = reinterpret_cast<long long*>(matches0); a.m1 = reinterpret_cast<long long*>(matches1);
-        a.ms0 = mscores0; a.ms1 = mscores1;
+        a.m0 = am0; a.m1 = am1;
+        a.ms0 = as0; a.ms1 = as1;
         launch_assignment(a, s);
     }
+    if (do_prune)  // :500-508: back to the original indices; pruned points are unmatched with score 0
+        launch_lg_scatter_matches(am0, am1, as0, as1, IND, Mc, Nc, M, N, reinterpret_cast<long long*>(matches0), reinterpret_cast<long long*>(matches1),
+                                  mscores0, mscores1, s);
+    if (ad && ad->out_dims) { ad->out_dims[0] = Mc; ad->out_dims[1] = Nc; ad->out_dims[2] = last + 1; }
     if (ref_desc0) HIPCHK(hipMemcpyAsync(ref_desc0, X, T0 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (ref_desc1) HIPCHK(hipMemcpyAsync(ref_desc1, X + T0 * 256, T1 * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
     HIPCHK(hipGetLastError());
     return 0;
+}
+
+int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
+                  const float* size0, const float* size1, int B, int M, int N, int64_t* matches0, int64_t* matches1, float* mscores0,
+                  float* mscores1, float* log_assignment, float* ref_desc0, float* ref_desc1, void* stream) {
+    return lg_run(h, conf, kpts0, kpts1, desc0, desc1, size0, size1, B, M, N, matches0, matches1, mscores0, mscores1, log_assignment, ref_desc0,
+                  ref_desc1, stream, nullptr);
+}
+
+int mg_lg_forward_adaptive(mg_handle h, const mg_lg_conf* conf, float depth_confidence, float width_confidence, const float* kpts0,
+                           const float* kpts1, const float* desc0, const float* desc1, const float* size0, const float* size1, int M, int N,
+                           int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment, float* ref_desc0,
+                           float* ref_desc1, int32_t* prune0, int32_t* prune1, int32_t* out_dims, void* stream) {
+    if (!prune0 || !prune1 || !out_dims) return fail(MG_ERR_ARG, "NULL argument");
+    LgAdaptive ad;
+    ad.depth = depth_confidence; ad.width = width_confidence; ad.prune0 = prune0; ad.prune1 = prune1; ad.out_dims = out_dims;
+    return lg_run(h, conf, kpts0, kpts1, desc0, desc1, size0, size1, 1, M, N, matches0, matches1, mscores0, mscores1, log_assignment, ref_desc0,
+                  ref_desc1, stream, &ad);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -227,6 +227,33 @@ struct AssignArgs {
 };
 void launch_assignment(const AssignArgs& a, hipStream_t s);
 
+// adaptive depth / width (lightglue.py:62-88,473-508,536-560), batch 1: token rows = image-0 rows (M) then image-1 rows (N)
+void launch_lg_adaptive_init(int* ind, int* prune0, int* prune1, int M, int N, hipStream_t s);   // ind = arange per image, prune = 1
+void launch_lg_count_below(const float* z, int T, float thr, int* count, hipStream_t s);         // #{ sigmoid(z) < thr }
+struct LgPruneArgs {
+    const float* z = nullptr;    // (M+N) matchability logits of the current tokens
+    const float* zt = nullptr;   // (M+N) token-confidence logits, or null (no early stopping)
+    float thr_tok = 0.f;         // confidence_threshold(layer)
+    float thr_keep = 0.f;        // 1 - width_confidence
+    int M = 0, N = 0;            // current token counts
+    const int* ind = nullptr;    // (M+N) original index of every current token
+    int* ind_out = nullptr;      // compacted
+    int* prune0 = nullptr;       // (M_orig) / (N_orig): += 1 for every survivor
+    int* prune1 = nullptr;
+    int* src = nullptr;          // (M+N) workspace: source row of every output row
+    int* counts = nullptr;       // (2) survivors per image
+    const float* x = nullptr;    // token rows to compact: fp32 (T,256), SH8 (T,256) (may be null), encodings (T,64)
+    const void* xs = nullptr;
+    const float* enc = nullptr;
+    float* x_out = nullptr;
+    void* xs_out = nullptr;
+    float* enc_out = nullptr;
+};
+void launch_lg_prune(const LgPruneArgs& a, hipStream_t s);                                        // keep flags, ordered compaction of ind, src map, counts
+void launch_lg_prune_gather(const LgPruneArgs& a, int M_new, int N_new, hipStream_t s);          // rows follow
+void launch_lg_scatter_matches(const long long* m0, const long long* m1, const float* s0, const float* s1, const int* ind, int Mc, int Nc, int M, int N,
+                               long long* out_m0, long long* out_m1, float* out_s0, float* out_s1, hipStream_t s);
+
 // ---- sg_misc.hip : SuperGlue keypoint-encoder input + log-domain Sinkhorn ---------------------------
 void launch_sg_kenc_input(const float* k0, const float* k1, const float* s0, const float* s1, const float* size0, const float* size1, int B,
                           int M, int N, float* out, hipStream_t s);

@@ -297,7 +297,121 @@ __global__ __launch_bounds__(256) void assign_filter(const AssignArgs p) {
     }
 }
 
+// ---- adaptive depth / width (batch 1) ------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void lg_adaptive_init_kernel(int* ind, int* prune0, int* prune1, int M, int N) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i < M) { ind[i] = i; prune0[i] = 1; }
+    else if (i < M + N) { ind[i] = i - M; prune1[i - M] = 1; }
+}
+
+__device__ __forceinline__ float sigmoidf_(float z) { return 1.f / (1.f + expf(-z)); }
+
+__global__ __launch_bounds__(256) void lg_count_below_kernel(const float* __restrict__ z, int T, float thr, int* count) {
+    __shared__ int s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    int n = 0;
+    for (int i = threadIdx.x; i < T; i += 256) n += sigmoidf_(z[i]) < thr ? 1 : 0;
+    atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0) *count = s_n;
+}
+
+// get_pruning_mask (lightglue.py:541-549): keep = matchability > 1 - width_confidence, OR the token is not yet confident.
+// One workgroup per image: ordered compaction of the original-index list, source map for the row gather, prune counter of survivors.
+__global__ __launch_bounds__(256) void lg_prune_kernel(const LgPruneArgs p) {
+    __shared__ int s_wsum[4];
+    __shared__ int s_base;
+    const int img = blockIdx.x, t = threadIdx.x, lane = t & 63, wave = t >> 6;
+    const int n = img ? p.N : p.M, off = img ? p.M : 0;
+    int* prune = img ? p.prune1 : p.prune0;
+    if (t == 0) s_base = 0;
+    __syncthreads();
+    for (int k0 = 0; k0 < n; k0 += 256) {
+        const int k = k0 + t;
+        int keep = 0;
+        if (k < n) {
+            keep = sigmoidf_(p.z[off + k]) > p.thr_keep;
+            if (p.zt) keep |= sigmoidf_(p.zt[off + k]) <= p.thr_tok;
+        }
+        const unsigned long long m = __ballot(keep);
+        const int before = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == 0) s_wsum[wave] = __popcll(m);
+        __syncthreads();
+        int o = s_base;
+        for (int w = 0; w < wave; ++w) o += s_wsum[w];
+        if (keep) {
+            const int d = o + before, orig = p.ind[off + k];
+            p.src[off + d] = k;          // per-image source row; destinations are re-based once both counts are known
+            p.ind_out[off + d] = orig;   // staged at the OLD offset of the image, moved by the gather pass
+            prune[orig] += 1;
+        }
+        __syncthreads();
+        if (t == 0) s_base += s_wsum[0] + s_wsum[1] + s_wsum[2] + s_wsum[3];
+        __syncthreads();
+    }
+    if (t == 0) p.counts[img] = s_base;
+}
+
+// rows follow: new row r (image-0 rows [0, Mn), image-1 rows [Mn, Mn+Nn)) <- old row off_old + src; one wave per row
+__global__ __launch_bounds__(256) void lg_prune_gather_kernel(const LgPruneArgs p, int Mn, int Nn, int* ind_final) {
+    const int lane = threadIdx.x & 63;
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (r >= Mn + Nn) return;
+    const int img = r >= Mn, rr = img ? r - Mn : r, off_old = img ? p.M : 0;
+    const int srow = off_old + p.src[off_old + rr];
+    *reinterpret_cast<f32x4*>(p.x_out + (long long)r * 256 + lane * 4) = *reinterpret_cast<const f32x4*>(p.x + (long long)srow * 256 + lane * 4);
+    if (p.xs) reinterpret_cast<u32x4*>(p.xs_out)[(long long)r * 64 + lane] = reinterpret_cast<const u32x4*>(p.xs)[(long long)srow * 64 + lane];
+    p.enc_out[(long long)r * 64 + lane] = p.enc[(long long)srow * 64 + lane];
+    if (lane == 0) ind_final[r] = p.ind_out[off_old + rr];
+}
+
+// lightglue.py:500-508: m0_[ind0] = where(m0 == -1, -1, ind1[m0]); scores likewise; everything else -1 / 0
+__global__ __launch_bounds__(256) void lg_scatter_matches_kernel(const long long* m0, const long long* m1, const float* s0, const float* s1, const int* ind,
+                                                                int Mc, int Nc, int M, int N, long long* o0, long long* o1, float* os0, float* os1, int phase) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (phase == 0) {
+        if (i < M) { o0[i] = -1; os0[i] = 0.f; }
+        else if (i < M + N) { o1[i - M] = -1; os1[i - M] = 0.f; }
+    } else {
+        if (i < Mc) {
+            const long long j = m0[i];
+            o0[ind[i]] = j < 0 ? -1 : (long long)ind[Mc + j];
+            os0[ind[i]] = s0[i];
+        } else if (i < Mc + Nc) {
+            const int k = i - Mc;
+            const long long j = m1[k];
+            o1[ind[Mc + k]] = j < 0 ? -1 : (long long)ind[j];
+            os1[ind[Mc + k]] = s1[k];
+        }
+    }
+}
+
 }  // namespace
+
+void launch_lg_adaptive_init(int* ind, int* prune0, int* prune1, int M, int N, hipStream_t s) {
+    hipLaunchKernelGGL(lg_adaptive_init_kernel, dim3((M + N + 255) / 256), dim3(256), 0, s, ind, prune0, prune1, M, N);
+}
+
+void launch_lg_count_below(const float* z, int T, float thr, int* count, hipStream_t s) {
+    hipLaunchKernelGGL(lg_count_below_kernel, dim3(1), dim3(256), 0, s, z, T, thr, count);
+}
+
+void launch_lg_prune(const LgPruneArgs& a, hipStream_t s) { hipLaunchKernelGGL(lg_prune_kernel, dim3(2), dim3(256), 0, s, a); }
+
+void launch_lg_prune_gather(const LgPruneArgs& a, int M_new, int N_new, hipStream_t s) {
+    // the compacted index list is staged in ind_out at the old image offsets; its final copy (new offsets) goes to the tail of `src`'s buffer
+    // and is copied back, so that ind_out ends up [image-0 survivors | image-1 survivors]
+    int* tmp = a.src + a.M + a.N;
+    hipLaunchKernelGGL(lg_prune_gather_kernel, dim3((M_new + N_new + 3) / 4), dim3(256), 0, s, a, M_new, N_new, tmp);
+    (void)hipMemcpyAsync(a.ind_out, tmp, sizeof(int) * (size_t)(M_new + N_new), hipMemcpyDeviceToDevice, s);
+}
+
+void launch_lg_scatter_matches(const long long* m0, const long long* m1, const float* s0, const float* s1, const int* ind, int Mc, int Nc, int M, int N,
+                               long long* out_m0, long long* out_m1, float* out_s0, float* out_s1, hipStream_t s) {
+    hipLaunchKernelGGL(lg_scatter_matches_kernel, dim3((M + N + 255) / 256), dim3(256), 0, s, m0, m1, s0, s1, ind, Mc, Nc, M, N, out_m0, out_m1, out_s0, out_s1, 0);
+    hipLaunchKernelGGL(lg_scatter_matches_kernel, dim3((Mc + Nc + 255) / 256), dim3(256), 0, s, m0, m1, s0, s1, ind, Mc, Nc, M, N, out_m0, out_m1, out_s0, out_s1, 1);
+}
 
 void launch_posenc(const float* kpts0, const float* kpts1, const float* size0, const float* size1, const float* Wr, int B, int M,
                    int N, float* enc, hipStream_t s) {

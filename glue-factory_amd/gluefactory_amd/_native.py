@@ -20,7 +20,7 @@ MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN, MG_SAMPLE_CORNER = 0, 1, 2, 3
 # every symbol include/matchglue.h declares (checked by tests/test_abi.py)
 EXPORTS = [
     "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_precision", "mg_set_weight", "mg_weights_ready",
-    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_sg_forward", "mg_gs_forward", "mg_wf_filter", "mg_nn_forward", "mg_debug_request", "mg_debug_read",
+    "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_lg_forward_adaptive", "mg_sg_forward", "mg_gs_forward", "mg_wf_filter", "mg_nn_forward", "mg_debug_request", "mg_debug_read",
     "mg_profile_enable", "mg_profile_read", "mg_test_linear", "mg_test_attention",
 ]
 
@@ -78,6 +78,7 @@ def lib():
                                c_void_p, c_void_p]
     L.mg_sp_sample.argtypes = [c_void_p, POINTER(SpConf), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.mg_lg_forward.argtypes = [c_void_p, POINTER(LgConf)] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 8
+    L.mg_lg_forward_adaptive.argtypes = [c_void_p, POINTER(LgConf), c_float, c_float] + [c_void_p] * 6 + [c_int] * 2 + [c_void_p] * 9 + [POINTER(c_int32), c_void_p]
     L.mg_sg_forward.argtypes = [c_void_p, POINTER(SgConf)] + [c_void_p] * 8 + [c_int] * 3 + [c_void_p] * 7
     L.mg_gs_forward.argtypes = [c_void_p, POINTER(GsConf)] + [c_void_p] * 14 + [c_int] * 5 + [c_void_p] * 12
     L.mg_wf_filter.argtypes = [c_void_p] + [c_void_p] * 5 + [c_int] * 3 + [c_float] + [c_void_p] * 5
@@ -215,6 +216,37 @@ class Engine:
         _check(lib().mg_lg_forward(self._h, ctypes.byref(conf), _ptr(k0), _ptr(k1), _ptr(d0), _ptr(d1), _ptr(s0), _ptr(s1), B, M, N,
                                    _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1), _ptr(la), _ptr(r0), _ptr(r1), _stream(dev)))
         return m0, m1, ms0, ms1, la, r0, r1
+
+    def lg_forward_adaptive(self, conf, depth_confidence, width_confidence, k0, k1, d0, d1, size0=None, size1=None, want_log_assignment=True):
+        """Adaptive depth / width LightGlue, batch 1.  Returns matches / scores in the original indices, the log assignment and the
+        final descriptors of the surviving points, the prune counters and (M', N', layers run)."""
+        dev = self.device
+        k0, k1, d0, d1 = (_f32(t, dev) for t in (k0, k1, d0, d1))
+        B, M, _ = k0.shape
+        N = k1.shape[1]
+        if B != 1:
+            raise RuntimeError("adaptive depth / width needs batch 1 (lightglue.py:476,:481)")
+        if d0.shape != (1, M, 256) or d1.shape != (1, N, 256):
+            raise RuntimeError(f"descriptors must be (1,K,256); got {tuple(d0.shape)} / {tuple(d1.shape)}")
+        s0 = None if size0 is None else _f32(size0, dev).reshape(-1, 2)[:1].contiguous()
+        s1 = None if size1 is None else _f32(size1, dev).reshape(-1, 2)[:1].contiguous()
+        m0 = torch.empty(1, M, dtype=torch.int64, device=dev)
+        m1 = torch.empty(1, N, dtype=torch.int64, device=dev)
+        ms0 = torch.empty(1, M, device=dev)
+        ms1 = torch.empty(1, N, device=dev)
+        la = torch.empty((M + 1) * (N + 1), device=dev) if want_log_assignment else None
+        r0 = torch.empty(M, 256, device=dev)
+        r1 = torch.empty(N, 256, device=dev)
+        p0 = torch.empty(1, M, dtype=torch.int32, device=dev)
+        p1 = torch.empty(1, N, dtype=torch.int32, device=dev)
+        dims = (c_int32 * 3)()
+        _check(lib().mg_lg_forward_adaptive(self._h, ctypes.byref(conf), float(depth_confidence), float(width_confidence), _ptr(k0), _ptr(k1), _ptr(d0),
+                                            _ptr(d1), _ptr(s0), _ptr(s1), M, N, _ptr(m0), _ptr(m1), _ptr(ms0), _ptr(ms1), _ptr(la), _ptr(r0), _ptr(r1),
+                                            _ptr(p0), _ptr(p1), dims, _stream(dev)))
+        Mc, Nc, layers = int(dims[0]), int(dims[1]), int(dims[2])
+        if la is not None:
+            la = la[: (Mc + 1) * (Nc + 1)].reshape(1, Mc + 1, Nc + 1)
+        return m0, m1, ms0, ms1, la, r0[None, :Mc], r1[None, :Nc], p0, p1, layers
 
     # -- SuperGlue -------------------------------------------------------------------------------
     def sg_forward(self, conf, k0, k1, d0, d1, sc0, sc1, size0, size1, want_log_assignment=True, want_cost=True):

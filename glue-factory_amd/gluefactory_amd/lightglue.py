@@ -7,8 +7,10 @@ same conf keys (:307-327), same required inputs (`keypoints0/1`, `descriptors0/1
 same state_dict keys (incl. the legacy `self_attn.{i}` -> `transformers.{i}.self_attn` rename, :378-385).
 The forward is one call into libmatchglue (`mg_lg_forward`).
 
-Adaptive depth / width (:473-493) is dead and broken in the reference fork (undefined
-`confidence_thresholds`); the keys are accepted and must stay <= 0.
+Adaptive depth / width (:468-508): `width_confidence` > 0 (point pruning) runs in the reference and is reproduced
+(`mg_lg_forward_adaptive`, pinned by tests/golden/lightglue_adaptive.npz); `depth_confidence` > 0 (early stopping)
+raises AttributeError in the reference fork (undefined `self.confidence_thresholds`, :556) -- it is built with the
+evident intent (= upstream LightGlue: thresholds from `confidence_threshold()`).  Both need batch 1, as in the reference.
 """
 import torch
 
@@ -44,8 +46,6 @@ class LightGlue(NativeModel):
             raise NotImplementedError("built for 256-d descriptors and 4 heads (SuperPoint + LightGlue)")
         if conf.add_scale_ori:
             raise NotImplementedError("add_scale_ori (SIFT/DISK inputs) is outside the SuperPoint+LightGlue path")
-        if conf.depth_confidence > 0 or conf.width_confidence > 0:
-            raise NotImplementedError("adaptive depth/width is disabled in every shipped config and broken in the reference fork")
         self._init_weights(conf)
 
     def _rename_keys(self, sd):
@@ -65,6 +65,21 @@ class LightGlue(NativeModel):
             size1 = data["view1"].get("image_size")
         eng = self.engine(k0.device)
         nc = _native.LgConf(int(self.conf.n_layers), int(self.conf.num_heads), float(self.conf.filter_threshold))
+        if not self.training and (self.conf.depth_confidence > 0 or self.conf.width_confidence > 0):
+            assert k0.shape[0] == 1  # lightglue.py:476,:481
+            m0, m1, ms0, ms1, la, r0, r1, p0, p1, layers = eng.lg_forward_adaptive(
+                nc, float(self.conf.depth_confidence), float(self.conf.width_confidence), k0, k1, data["descriptors0"], data["descriptors1"],
+                size0, size1, want_log_assignment=True)
+            pruning = self.conf.width_confidence > 0
+            pred = {
+                "matches0": m0, "matches1": m1, "matching_scores0": ms0, "matching_scores1": ms1,
+                "ref_descriptors0": r0[:, None], "ref_descriptors1": r1[:, None], "log_assignment": la,
+                # :463-466 int64 counters when pruning, :509-511 n_layers (float) otherwise
+                "prune0": p0.to(torch.int64) if pruning else torch.full_like(ms0, float(self.conf.n_layers)),
+                "prune1": p1.to(torch.int64) if pruning else torch.full_like(ms1, float(self.conf.n_layers)),
+            }
+            self.last_layers_run = layers
+            return pred
         m0, m1, ms0, ms1, la, r0, r1 = eng.lg_forward(
             nc, k0, k1, data["descriptors0"], data["descriptors1"], size0, size1,
             want_log_assignment=bool(self.conf.return_log_assignment), want_ref=True,

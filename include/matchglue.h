@@ -65,7 +65,7 @@ int mg_create(int device, mg_handle* out);
 int mg_destroy(mg_handle h);
 const char* mg_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
-#define MG_ABI_VERSION 7 /* bumped whenever an entry point or a conf struct changes */
+#define MG_ABI_VERSION 8 /* bumped whenever an entry point or a conf struct changes */
 int mg_abi_version(void);   /* == MG_ABI_VERSION of the header the library was built from */
 
 /* -- arithmetic ------------------------------------------------------------------------------
@@ -121,6 +121,25 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
                   const float* desc0, const float* desc1, const float* size0, const float* size1,
                   int B, int M, int N, int64_t* matches0, int64_t* matches1, float* mscores0,
                   float* mscores1, float* log_assignment, float* ref_desc0, float* ref_desc1, void* stream);
+
+/* Adaptive depth / width (lightglue.py:62-88,468-508,536-560), batch 1 as the reference asserts (:476,:481).
+ * After every layer but the last:
+ *   depth_confidence > 0: token confidences sigmoid(token_confidence.i(x)); stop when 1 - #{conf < t_i} / (M + N) > depth_confidence,
+ *     t_i = clip(0.8 + 0.1 exp(-4 i / n_layers), 0, 1) (:536-539, :551-560).  The fork reads an undefined `self.confidence_thresholds`
+ *     there (AttributeError at the first call), so this half follows its evident intent = upstream LightGlue; parity unpinned.
+ *   width_confidence > 0: points with sigmoid(log_assignment.i.matchability(x)) <= 1 - width_confidence are dropped from both the
+ *     descriptors and the encodings -- unless early stopping is on and the point is not yet confident (get_pruning_mask, :541-549).
+ *     This half runs in the reference and is pinned by tests/golden/lightglue_adaptive.npz.
+ * The assignment uses the head of the last layer that ran (:498-499).  matches / scores come back in the ORIGINAL indices (pruned
+ * points: -1 / 0, :500-508); prune0/1 (M)/(N) int32 = 1 + pruning rounds survived (:463-466,:487,:495).
+ * log_assignment (optional, room for (M+1)(N+1) floats) is (M'+1, N'+1) and ref_desc0/1 (optional, (M,256)/(N,256)) hold M' / N'
+ * rows for the surviving points; out_dims (HOST, 3 ints) receives M', N' and the number of layers run.  Synchronises the stream
+ * once per layer (the decisions are made on the host, as `if self.check_if_stop(...)` / `torch.where` do in the reference). */
+int mg_lg_forward_adaptive(mg_handle h, const mg_lg_conf* conf, float depth_confidence, float width_confidence,
+                           const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
+                           const float* size0, const float* size1, int M, int N, int64_t* matches0, int64_t* matches1,
+                           float* mscores0, float* mscores1, float* log_assignment, float* ref_desc0, float* ref_desc1,
+                           int32_t* prune0, int32_t* prune1, int32_t* out_dims, void* stream);
 
 /* -- SuperGlue -------------------------------------------------------------
  * gluefactory_nonfree/superglue.py:253-307: keypoint encoder (MLP on (x,y,score)), 18-layer attentional

@@ -358,11 +358,21 @@ def filter_matches(S, th):
     return torch.where(ok0, m0, -1), torch.where(ok1, m1, -1), ms0, ms1, r.indices, c.indices
 
 
-LG_DEFAULTS = dict(n_layers=9, num_heads=4, filter_threshold=0.0)
+LG_DEFAULTS = dict(n_layers=9, num_heads=4, filter_threshold=0.0, depth_confidence=-1, width_confidence=-1)
+
+
+def lg_confidence_threshold(layer_index, n_layers):
+    """lightglue.py:536-539."""
+    return float(min(1.0, max(0.0, 0.8 + 0.1 * math.exp(-4.0 * layer_index / n_layers))))
 
 
 def lightglue_forward(data, W, collect_layers=(), **conf):
-    """lightglue.py:399-525 with depth/width adaptivity off (dead in every shipped config)."""
+    """lightglue.py:399-525.  With depth_confidence / width_confidence <= 0 (every shipped config) the plain 9-layer pass.
+
+    width_confidence > 0 restates the point pruning of :480-497 / :541-549 / :500-508 (it runs in the reference; pinned by
+    tests/golden/lightglue_adaptive.npz).  depth_confidence > 0 restates the early stopping of :474-479 / :551-560 with the
+    thresholds of `confidence_threshold()`: the fork reads an undefined `self.confidence_thresholds` there and raises, so this
+    half follows the evident intent (= upstream LightGlue) and has no reference output to be pinned to.  Both need batch 1."""
     cfg = {**LG_DEFAULTS, **conf}
     k0, k1 = data["keypoints0"], data["keypoints1"]
     size0 = size1 = None
@@ -379,7 +389,14 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
     e0 = fourier_encoding(k0, W["posenc.Wr.weight"])
     e1 = fourier_encoding(k1, W["posenc.Wr.weight"])
     L, H = cfg["n_layers"], cfg["num_heads"]
+    do_stop, do_prune = cfg["depth_confidence"] > 0, cfg["width_confidence"] > 0
+    b, m, n = d0.shape[0], d0.shape[1], d1.shape[1]
+    if do_stop or do_prune:
+        assert b == 1
+    ind0, ind1 = torch.arange(m)[None], torch.arange(n)[None]
+    prune0, prune1 = torch.ones_like(ind0), torch.ones_like(ind1)
     layers = {}
+    last = L - 1
     for i in range(L):
         p = f"transformers.{i}"
         d0 = self_block(d0, e0, W, p + ".self_attn", H)
@@ -389,8 +406,44 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
         d0, d1 = cross_block(d0, d1, W, p + ".cross_attn", H)
         if i in collect_layers:
             layers[i] = (d0.clone(), d1.clone())
-    S, sim = log_assignment(d0, d1, W, f"log_assignment.{L - 1}")
+        if i == L - 1 or not (do_stop or do_prune):
+            continue
+        thr = lg_confidence_threshold(i, L)
+        t0 = t1 = None
+        if do_stop:  # :62-72, :551-560
+            tw, tb = W[f"token_confidence.{i}.token.0.weight"], W[f"token_confidence.{i}.token.0.bias"]
+            t0, t1 = torch.sigmoid(F.linear(d0, tw, tb)).squeeze(-1), torch.sigmoid(F.linear(d1, tw, tb)).squeeze(-1)
+            conf_all = torch.cat([t0, t1], -1)
+            if 1.0 - (conf_all < thr).float().sum() / (m + n) > cfg["depth_confidence"]:
+                last = i
+                break
+        if do_prune:  # :480-497
+            mw, mb = W[f"log_assignment.{i}.matchability.weight"], W[f"log_assignment.{i}.matchability.bias"]
+            for side in (0, 1):
+                d, t = (d0, t0) if side == 0 else (d1, t1)
+                keep = torch.sigmoid(F.linear(d, mw, mb)).squeeze(-1) > (1 - cfg["width_confidence"])
+                if t is not None:
+                    keep = keep | (t <= thr)
+                kidx = torch.where(keep)[1]
+                if side == 0:
+                    ind0, d0, e0 = ind0.index_select(1, kidx), d0.index_select(1, kidx), e0.index_select(-2, kidx)
+                    prune0[:, ind0] += 1
+                else:
+                    ind1, d1, e1 = ind1.index_select(1, kidx), d1.index_select(1, kidx), e1.index_select(-2, kidx)
+                    prune1[:, ind1] += 1
+    S, sim = log_assignment(d0, d1, W, f"log_assignment.{last}")
     m0, m1, ms0, ms1, am0, am1 = filter_matches(S, cfg["filter_threshold"])
+    if do_prune:  # :500-508
+        m0_ = torch.full((b, m), -1, dtype=m0.dtype)
+        m1_ = torch.full((b, n), -1, dtype=m1.dtype)
+        m0_[:, ind0] = torch.where(m0 == -1, -1, ind1.gather(1, m0.clamp(min=0)))
+        m1_[:, ind1] = torch.where(m1 == -1, -1, ind0.gather(1, m1.clamp(min=0)))
+        s0_, s1_ = torch.zeros(b, m), torch.zeros(b, n)
+        s0_[:, ind0] = ms0
+        s1_[:, ind1] = ms1
+        m0, m1, ms0, ms1 = m0_, m1_, s0_, s1_
+    else:
+        prune0, prune1 = torch.ones_like(ms0) * L, torch.ones_like(ms1) * L
     return {
         "matches0": m0,
         "matches1": m1,
@@ -399,12 +452,15 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
         "ref_descriptors0": d0[:, None],
         "ref_descriptors1": d1[:, None],
         "log_assignment": S,
-        "prune0": torch.ones_like(ms0) * L,
-        "prune1": torch.ones_like(ms1) * L,
+        "prune0": prune0,
+        "prune1": prune1,
         "_argmax0": am0,
         "_argmax1": am1,
         "_sim": sim,
         "_layers": layers,
+        "_layers_run": last + 1,
+        "_ind0": ind0,
+        "_ind1": ind1,
     }
 
 

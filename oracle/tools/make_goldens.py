@@ -229,6 +229,46 @@ def gold_lightglue():
 
 
 # ---------------------------------------------------------------- (4b) SuperGlue
+def lg_adaptive_pair(M, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    size = torch.tensor([[640.0, 480.0]])
+    k0 = torch.rand(1, M, 2, generator=g) * size * 0.98 + 0.5
+    d0 = torch.nn.functional.normalize(torch.randn(1, M, 256, generator=g), dim=-1)
+    perm = (torch.randperm(max(M, N), generator=g)[:N] % M)[None]
+    k1 = torch.gather(k0, 1, perm[..., None].expand(-1, -1, 2)) * 0.9 + 2.0 * torch.randn(1, N, 2, generator=g)
+    d1 = torch.nn.functional.normalize(torch.gather(d0, 1, perm[..., None].expand(-1, -1, 256)) + 0.03 * torch.randn(1, N, 256, generator=g), dim=-1)
+    return {"keypoints0": k0, "keypoints1": k1, "descriptors0": d0, "descriptors1": d1, "view0": {"image_size": size}, "view1": {"image_size": size}}
+
+
+def gold_lightglue_adaptive():
+    """Point pruning (`width_confidence` > 0, lightglue.py:480-508) of the in-tree LightGlue run as is.  (`depth_confidence` > 0
+    raises AttributeError in this fork -- `self.confidence_thresholds` is never defined, :556 -- so early stopping has no
+    reference output; it is restated with the thresholds of `confidence_threshold()` and tested against the oracle only.)"""
+    Ref = get_model("matchers.lightglue")
+    arrs = {}
+    for tag, M, N, wseed, dseed, wc in (("a", 200, 180, 11, 5, 0.57), ("b", 200, 180, 12, 5, 0.55), ("c", 97, 130, 13, 6, 0.58)):
+        W = O.make_lg_weights(wseed, structured=True, final_gain=3.0, match_bias=0.0)
+        data = lg_adaptive_pair(M, N, dseed)
+        m = Ref({"weights": None, "width_confidence": wc, "filter_threshold": 0.1}).eval()
+        missing, unexpected = m.load_state_dict(W, strict=False)
+        assert not missing and not unexpected
+        p = m(data)
+        for k in ("keypoints0", "keypoints1", "descriptors0", "descriptors1"):
+            arrs[f"{tag}.{k}"] = data[k]
+        arrs[f"{tag}.size"] = data["view0"]["image_size"]
+        arrs[f"{tag}.width_confidence"] = torch.tensor(wc)
+        for k in ("matches0", "matches1", "matching_scores0", "matching_scores1", "log_assignment", "prune0", "prune1", "ref_descriptors0", "ref_descriptors1"):
+            arrs[f"{tag}.{k}"] = p[k]
+        try:
+            Ref({"weights": None, "depth_confidence": 0.95, "filter_threshold": 0.1}).eval()(data)
+            raise SystemExit("the reference's early stopping ran: pin it with a golden instead of the restatement")
+        except AttributeError as e:
+            assert "confidence_thresholds" in str(e)
+        print("lightglue adaptive", tag, "survivors", tuple(p["log_assignment"].shape), "matches", int((p["matches0"] > -1).sum()),
+              "prune0 histogram", torch.bincount(p["prune0"][0]).tolist())
+    save("lightglue_adaptive", **arrs)
+
+
 def gold_superglue():
     import gluefactory_nonfree.superglue as ref_sg
 
@@ -485,6 +525,7 @@ if __name__ == "__main__":
     gold_nms_topk()
     gold_superpoint(boat)
     gold_lightglue()
+    gold_lightglue_adaptive()
     gold_superglue()
     gold_nn()
     gold_export()

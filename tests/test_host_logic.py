@@ -84,8 +84,10 @@ def test_no_cpu_fallback():
 def test_rejected_options():
     from gluefactory_amd import get_model
 
+    lg = get_model("lightglue")({"depth_confidence": 0.95, "width_confidence": 0.99})  # adaptive depth / width is built (batch 1)
+    assert lg.conf.depth_confidence == 0.95
     with pytest.raises(NotImplementedError):
-        get_model("lightglue")({"depth_confidence": 0.95})
+        get_model("lightglue")({"add_scale_ori": True})
     with pytest.raises(NotImplementedError):
         get_model("superpoint")({"refinement_radius": 2})
     with pytest.raises(FileNotFoundError):

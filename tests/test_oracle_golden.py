@@ -227,3 +227,21 @@ def test_wireframe_matches_reference(golden):
     # the fixture exercises both GPU steps: keypoints are removed, endpoints are merged
     assert g["merge.keypoints"].shape[1] - int(g["merge.num_junctions"][0]) < sp["keypoints"].shape[1]
     assert int(g["merge.num_junctions"][0]) < 2 * g["merge.in.lines"].shape[1]
+
+
+def _lga_data(g, tag):
+    return {"keypoints0": g[tag + ".keypoints0"], "keypoints1": g[tag + ".keypoints1"], "descriptors0": g[tag + ".descriptors0"],
+            "descriptors1": g[tag + ".descriptors1"], "view0": {"image_size": g[tag + ".size"]}, "view1": {"image_size": g[tag + ".size"]}}
+
+
+def test_lightglue_point_pruning_matches_reference(golden):
+    """`width_confidence` > 0 of the in-tree LightGlue (lightglue.py:480-508), run by oracle/tools/make_goldens.py."""
+    g = golden("lightglue_adaptive")
+    for tag, wseed in (("a", 11), ("b", 12), ("c", 13)):
+        W = O.make_lg_weights(wseed, structured=True, final_gain=3.0, match_bias=0.0)
+        p = O.lightglue_forward(_lga_data(g, tag), W, filter_threshold=0.1, width_confidence=float(g[tag + ".width_confidence"]))
+        for k in ("matches0", "matches1", "prune0", "prune1"):
+            assert torch.equal(p[k], g[f"{tag}.{k}"]), (tag, k)
+        for k in ("matching_scores0", "matching_scores1", "log_assignment", "ref_descriptors0", "ref_descriptors1"):
+            torch.testing.assert_close(p[k], g[f"{tag}.{k}"], rtol=0, atol=1e-6)
+        assert p["log_assignment"].shape[1] - 1 < p["matches0"].shape[1]  # points were really pruned
