@@ -1174,13 +1174,14 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
             pa.z = Z; pa.zt = do_stop ? ZT : nullptr; pa.thr_tok = thr; pa.thr_keep = (float)(1.0 - (double)ad->width);
             pa.M = Mc; pa.N = Nc; pa.ind = IND; pa.ind_out = IND2; pa.prune0 = ad->prune0; pa.prune1 = ad->prune1; pa.src = reinterpret_cast<int32_t*>(ST);
             pa.counts = CNT;
-            pa.x = X; pa.xs = XS; pa.enc = ENC; pa.x_out = X2; pa.xs_out = XS2; pa.enc_out = ENC2;
+            pa.x = X; pa.xs = f16 ? XS : nullptr; pa.enc = ENC; pa.x_out = X2; pa.xs_out = f16 ? XS2 : nullptr; pa.enc_out = ENC2;  // no SH8 copy in f32 mode
             launch_lg_prune(pa, s);
             int32_t cnt[2] = {0, 0};
             HIPCHK(hipMemcpyAsync(cnt, CNT, 2 * sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             launch_lg_prune_gather(pa, cnt[0], cnt[1], s);
-            std::swap(X, X2); std::swap(XS, XS2); std::swap(ENC, ENC2); std::swap(IND, IND2);
+            std::swap(X, X2); std::swap(ENC, ENC2); std::swap(IND, IND2);
+            if (f16) std::swap(XS, XS2);
             Mc = cnt[0]; Nc = cnt[1];
             T0 = (size_t)Mc; T = (size_t)Mc + Nc;
             if (Mc < 1 || Nc < 1) return fail(MG_ERR_STATE, "point pruning removed every keypoint of an image");

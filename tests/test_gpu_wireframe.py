@@ -64,12 +64,22 @@ def test_wf_filter_vs_torch(dev, K, E, r):
     okp, osc, ods, cnt = (t.cpu() for t in eng.wf_filter(kp, sc, ds, ep, r, num_valid=nv))
     for b in range(B):
         dist = torch.norm(kp[b, :, None] - ep[b][None], dim=-1)
-        if E:
-            assert not bool(((dist - r).abs() < 1e-4).any())  # the seeded data keeps clear of the radius
-        keep = ~torch.any(dist < r, dim=1) & (torch.arange(K) < nv[b])
-        n = int(keep.sum())
-        assert int(cnt[b]) == n
-        assert torch.equal(okp[b, :n], kp[b][keep]) and torch.equal(osc[b, :n], sc[b][keep]) and torch.equal(ods[b, :n], ds[b][keep])
+        valid = torch.arange(K) < nv[b]
+        keep = ~torch.any(dist < r, dim=1) & valid
+        # a keypoint whose nearest endpoint sits within 1e-5 of the radius may fall either way (sqrt / sum rounding); with millions of
+        # pairs a few do: they are excluded from the exact comparison, everything else must agree row for row
+        border = (torch.any((dist - r).abs() < 1e-5, dim=1) if E else torch.zeros(K, dtype=torch.bool)) & valid
+        n = int(cnt[b])
+        assert int((keep & ~border).sum()) <= n <= int((keep | border).sum())
+        got_rows = {tuple(v) for v in okp[b, :n].tolist()}
+        for k in torch.nonzero(valid & ~border).flatten().tolist():
+            assert (tuple(kp[b, k].tolist()) in got_rows) == bool(keep[k]), (b, k)
+        if not bool(border.any()):
+            assert torch.equal(okp[b, :n], kp[b][keep]) and torch.equal(osc[b, :n], sc[b][keep]) and torch.equal(ods[b, :n], ds[b][keep])
+        else:  # order preserved, rows travel together
+            src = [int(torch.nonzero((kp[b] == okp[b, i]).all(-1))[0]) for i in range(n)]
+            assert src == sorted(src)
+            assert torch.equal(osc[b, :n], sc[b][src]) and torch.equal(ods[b, :n], ds[b][src])
         assert bool((okp[b, n:] == 0).all()) and bool((osc[b, n:] == 0).all()) and bool((ods[b, n:] == 0).all())
 
 
