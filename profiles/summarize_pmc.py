@@ -20,6 +20,11 @@ SHORT = {
     "attention_f16x3_kernel": "lg.attn",
     "nms_kernel": "sp.nms",
     "ln_gelu_kernel": "lg.ln_gelu",
+    "ffn_f16x3_kernel": "lg.ffn",
+    "heads_f16x3_kernel": "sp.heads",
+    "softmax_d2s_kernel": "sp.softmax_d2s",
+    "select_kernel": "sp.select",
+    "sample_kernel": "sp.sample",
 }
 
 
