@@ -6,8 +6,11 @@
 // is bound by L2->LDS traffic (42 B/clk/CU at full rate); 256x256 halves the bytes per MFMA:
 //   * both operands arrive SH8, so a 16-deep stage row is 64 contiguous bytes = four 16-byte pieces,
 //     moved to LDS by LDS-DMA (global_load_lds) with the piece index XOR (row>>2)&3 applied on the
-//     source side -> no ds_write traffic, every fragment ds_read_b128 conflict-free; the token stream
-//     (HBM) and the weight stream (L2) are issued by different waves into rings of their own depth;
+//     source side -> no ds_write traffic, every fragment ds_read_b128 conflict-free;
+//   * one barrier per stage and nothing between it and the first MFMA: the fragments of stage k+1 are read into a
+//     second register set under the MFMAs of stage k, and every wave issues its four DMA pieces of stage k+3 (into the
+//     slot stage k just left) between those MFMAs -- MFMA-first, one filler per MFMA (the structure of ffn_f16.hip, where
+//     the in-kernel stamps showed the older "dedicated loader waves + reads behind the barrier" loop at 56 % MFMA occupancy);
 //   * the weight tile is the A operand (rows = features) and the token tile the B operand (lanes), so a
 //     lane owns one token: after one v_permlane32_swap per register pair it holds 16 consecutive features
 //     -- rotary pairs are adjacent registers (no shuffle), the residual / fp32 store is 64 contiguous
@@ -17,14 +20,14 @@
 #include "common.h"
 #include "kernels.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TN = 256, TM = 256, BK = 16, GT = 512;  // 8 waves: 2 (features) x 4 (tokens), each 128 x 64
-#ifndef MG_TSLOTS  // ring depths are compile-time knobs: (7,2) / (6,3) / (5,4) / (4,3) measured within 2 % of each other
-#define MG_TSLOTS 5
-#define MG_WSLOTS 4
-#endif
-constexpr int TSLOTS = MG_TSLOTS, WSLOTS = MG_WSLOTS;  // LDS rings: token stages (HBM) run TSLOTS-1 ahead, weight stages (L2) WSLOTS-1 ahead
+constexpr int RS = 3;                                  // ring slots per operand: stage k+3 is issued into the slot stage k just left
+constexpr int TSLOTS = RS, WSLOTS = RS;
+#define PIN() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ int swz(int row, int q) { return row * 4 + (q ^ ((row >> 2) & 3)); }  // 64-byte rows
 
@@ -78,55 +81,43 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
 
     const int nk = p.K / BK;
     const int wu = __builtin_amdgcn_readfirstlane(wave);
-    const bool tok_wave = wu < 4;  // waves 0-3 stream the token operand, waves 4-7 the weights
-    const int lw = wu & 3;
+    const int i32 = lane & 31, h = lane >> 5;
+    const int lane_hi = swz(i32, 2 * h), lane_lo = swz(i32, 2 * h + 1);  // fragment piece index inside a tile whose first row is a multiple of 16
 
-    // A stage is one 16-deep k-step: 256 token rows x 64 B (from HBM) + 256 feature rows x 64 B (weights,
-    // L2-resident), moved to LDS by LDS-DMA (global_load_lds_dwordx4: no VGPR round trip, no ds_write;
-    // the DMA writes LDS linearly, so the XOR swizzle is applied to the per-lane SOURCE piece; rows
-    // past the edge are clamped, their outputs are never stored).
-    // These GEMMs are HBM-bound (K = 256..512) and vmcnt retires in issue order, so the two operand
-    // streams are issued by DIFFERENT waves with their own ring depth: the token waves keep TSLOTS-1 stages
-    // (64 KB per CU, 16 MB chip-wide) in flight behind counted vmcnt waits, the weight waves WSLOTS-1.
-    auto issue_tok = [&](int kt) {
+    // A stage is one 16-deep k-step: 256 token rows x 64 B + 256 feature rows x 64 B, moved to LDS by LDS-DMA
+    // (global_load_lds_dwordx4: no VGPR round trip, no ds_write; the DMA writes LDS linearly, so the XOR swizzle is applied
+    // to the per-lane SOURCE piece; rows past the edge are clamped, their outputs are never stored).  32 pieces of 1 KB per
+    // stage: every wave issues two token pieces (2 wu, 2 wu + 1) and two weight pieces.
+    long long tok_off[2];
+    long long w_off[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int slot = (wu * 2 + j) * 64 + lane, row = slot >> 2, q = (slot & 3) ^ ((row >> 2) & 3);
+        tok_off[j] = (long long)min(m0 + row, p.M - 1);  // row index; the row stride depends on the source (A0 / A1)
+        tok_off[j] = tok_off[j] * 4 + q;                 // packed: row * 4 + piece (lda is applied per stage)
+        if (W_ROWMAJOR) w_off[j] = (long long)min(n0 + row, p.N - 1) * 4 + q;
+        else w_off[j] = (long long)(n0 + row) * 4 + q;
+    }
+    auto dma_tok = [&](int kt, int j) {
         const int k0 = kt * BK;
-        u32x4* ring = s_tokr + (kt % TSLOTS) * TM * 4;
         const u32x4* Asrc;
         int lda, kk;
         if (k0 < p.ksplit) { Asrc = A0; lda = p.lda0; kk = k0; } else { Asrc = A1; lda = p.lda1; kk = k0 - p.ksplit; }
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int slot = (lw * 4 + j) * 64 + lane, row = slot >> 2, qp = slot & 3;
-            const int q = qp ^ ((row >> 2) & 3);
-            const int gm = min(m0 + row, p.M - 1);
-            __builtin_amdgcn_global_load_lds(Asrc + (((long long)gm * lda + kk) >> 2) + q, ring + (lw * 4 + j) * 64, 16, 0, 0);
-        }
+        const long long row = tok_off[j] >> 2;
+        const int q = (int)(tok_off[j] & 3);
+        __builtin_amdgcn_global_load_lds(Asrc + ((row * lda + kk) >> 2) + q, s_tokr + (kt % RS) * TM * 4 + (wu * 2 + j) * 64, 16, 0, 0);
     };
-    auto issue_w = [&](int kt) {
+    auto dma_w = [&](int kt, int j) {
         const int k0 = kt * BK;
-        u32x4* ring = s_wr + (kt % WSLOTS) * TN * 4;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int slot = (lw * 4 + j) * 64 + lane, row = slot >> 2, qp = slot & 3;
-            const int q = qp ^ ((row >> 2) & 3);
-            const u32x4* src;
-            if (W_ROWMAJOR) {
-                const int gn = min(n0 + row, p.N - 1);
-                src = Wg + (((long long)gn * p.ldw + k0) >> 2) + q;
-            } else {
-                src = Wg + ((long long)(k0 >> 4) * p.Npad + n0 + row) * 4 + q;
-            }
-            __builtin_amdgcn_global_load_lds(src, ring + (lw * 4 + j) * 64, 16, 0, 0);
-        }
+        const u32x4* src;
+        if (W_ROWMAJOR) src = Wg + (((w_off[j] >> 2) * p.ldw + k0) >> 2) + (w_off[j] & 3);
+        else src = Wg + (long long)(k0 >> 4) * p.Npad * 4 + w_off[j];
+        __builtin_amdgcn_global_load_lds(src, s_wr + (kt % RS) * TN * 4 + (wu * 2 + j) * 64, 16, 0, 0);
     };
-
-    const int i32 = lane & 31, h = lane >> 5;
-    if (tok_wave) {
+    const int npro = min(RS, nk);
 #pragma unroll 1
-        for (int s0 = 0; s0 < TSLOTS - 1 && s0 < nk; ++s0) issue_tok(s0);
-    } else {
-#pragma unroll 1
-        for (int s0 = 0; s0 < WSLOTS - 1 && s0 < nk; ++s0) issue_w(s0);
+    for (int s0 = 0; s0 < npro; ++s0) {
+        dma_tok(s0, 0); dma_tok(s0, 1); dma_w(s0, 0); dma_w(s0, 1);
     }
     // per-feature epilogue parameters -> LDS (one global round trip per workgroup, under the DMA prologue)
     for (int i = t; i < TN; i += GT) {
@@ -136,57 +127,62 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
         s_par[TN + i] = (p.post_scale && ok) ? p.post_scale[f] : 1.f;
         s_par[2 * TN + i] = (p.post_shift && ok) ? p.post_shift[f] : 0.f;
     }
-    for (int kt = 0; kt < ((p.debug & 2) ? 0 : nk); ++kt) {
-        // each wave waits for ITS loads of stage kt: all but the younger stages of its own stream
-        if (tok_wave) {
-            const int ahead = min(TSLOTS - 2, nk - 1 - kt);
-            if (ahead == 6) asm volatile("s_waitcnt vmcnt(24)" ::: "memory");
-            else if (ahead == 5) asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
-            else if (ahead == 4) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else if (ahead == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            else if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        } else {
-            const int ahead = min(WSLOTS - 2, nk - 1 - kt);
-            if (ahead == 2) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else if (ahead == 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        }
-        __builtin_amdgcn_s_barrier();  // stage kt is complete in LDS; everyone is done with stage kt-1
-        if (tok_wave) {
-            if (kt + TSLOTS - 1 < nk) issue_tok(kt + TSLOTS - 1);  // into the slot stage kt-1 just vacated
-        } else {
-            if (kt + WSLOTS - 1 < nk) issue_w(kt + WSLOTS - 1);
-        }
-        const f16x8* st = reinterpret_cast<const f16x8*>(s_tokr + (kt % TSLOTS) * TM * 4);
-        const f16x8* sw = reinterpret_cast<const f16x8*>(s_wr + (kt % WSLOTS) * TN * 4);
-        f16x8 ah[4], al[4], bh[2], bl[2];
+    f16x8 ah[2][4], al[2][4], bh[2][2], bl[2][2];  // [register set][tile]
+    auto read_frag = [&](int set, int kt, int i) {  // fragment read i (0..11) of stage kt: hi halves first (they are used first)
+        const f16x8* st = reinterpret_cast<const f16x8*>(s_tokr + (kt % RS) * TM * 4) + wt * 64 * 4;
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_wr + (kt % RS) * TN * 4) + wf * 128 * 4;
+        if (i < 4) ah[set][i] = sw[lane_hi + i * 32 * 4];
+        else if (i < 6) bh[set][i - 4] = st[lane_hi + (i - 4) * 32 * 4];
+        else if (i < 8) bl[set][i - 6] = st[lane_lo + (i - 6) * 32 * 4];
+        else al[set][i - 8] = sw[lane_lo + (i - 8) * 32 * 4];
+    };
+    if (nk > 0 && !(p.debug & 2)) {
+        // stage 0 landed (mine): all but the younger stages' pieces (4 per stage)
+        if (npro >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+        else if (npro == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
 #pragma unroll
-        for (int ft = 0; ft < 4; ++ft) {
-            const int row = wf * 128 + ft * 32 + i32;
-            ah[ft] = sw[swz(row, 2 * h)];
-            al[ft] = sw[swz(row, 2 * h + 1)];
-        }
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-            const int row = wt * 64 + tt * 32 + i32;
-            bh[tt] = st[swz(row, 2 * h)];
-            bl[tt] = st[swz(row, 2 * h + 1)];
-        }
-        // product-major: consecutive MFMAs hit different accumulators; per accumulator the order stays hi.hi, hi.lo, lo.hi
+        for (int i = 0; i < 12; ++i) read_frag(0, 0, i);
+    }
+    // one stage: [my pieces of stage kt+1 landed] [my fragment reads of stage kt done] barrier, then the 24 MFMAs of stage kt
+    // (product-major: hi.hi, hi.lo, lo.hi; consecutive MFMAs hit different accumulators) with, from the third on, one filler each:
+    // the four DMA pieces of stage kt+3, then the twelve fragment reads of stage kt+1 into the other register set
+    auto stage = [&](auto set_c, int kt) {
+        constexpr int S = decltype(set_c)::value;
+        if (kt + 2 <= nk - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        const bool more_dma = kt + RS < nk, more_rd = kt + 1 < nk;
+        int slot_i = 0;
+        auto filler = [&]() {
+            const int f = slot_i++ - 2;
+            if (f >= 0 && f < 4) { if (more_dma) { if (f < 2) dma_tok(kt + RS, f); else dma_w(kt + RS, f - 2); } }
+            else if (f >= 4 && f < 16) { if (more_rd) read_frag(1 - S, kt + 1, f - 4); }
+            PIN();
+        };
+        PIN();
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) acc[ft][tt] = mfma16(ah[ft], bh[tt], acc[ft][tt]);
+            for (int tt = 0; tt < 2; ++tt) { acc[ft][tt] = mfma16(ah[S][ft], bh[S][tt], acc[ft][tt]); filler(); }
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) acc[ft][tt] = mfma16(ah[ft], bl[tt], acc[ft][tt]);
+            for (int tt = 0; tt < 2; ++tt) { acc[ft][tt] = mfma16(ah[S][ft], bl[S][tt], acc[ft][tt]); filler(); }
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
 #pragma unroll
-            for (int tt = 0; tt < 2; ++tt) acc[ft][tt] = mfma16(al[ft], bh[tt], acc[ft][tt]);
+            for (int tt = 0; tt < 2; ++tt) { acc[ft][tt] = mfma16(al[S][ft], bh[S][tt], acc[ft][tt]); filler(); }
+    };
+    if (!(p.debug & 2)) {
+#pragma unroll 1
+        for (int kt = 0; kt < nk; kt += 2) {
+            stage(std::integral_constant<int, 0>{}, kt);
+            if (kt + 1 < nk) stage(std::integral_constant<int, 1>{}, kt + 1);
+        }
     }
 
     // ---- epilogue ---------------------------------------------------------------------------------
