@@ -483,6 +483,7 @@ def two_view_forward(data, W_sp, W_lg, sp_conf, lg_conf, with_maps=False):
     pred.update({k: v for k, v in lg.items() if not k.startswith("_")})
     if with_maps:
         pred.update(maps)
+        pred["_sim"] = lg["_sim"]
     return pred
 
 

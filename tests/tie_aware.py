@@ -171,7 +171,11 @@ def check_two_view(p, ref, b, k_max, th, tag="", la_floor=1e-5, score_atol=None)
         got_la = to_oracle_order(p["log_assignment"][b][: M + 1, : N + 1] if p["log_assignment"].shape[1] == M + 1 else
                                  _crop_la(p["log_assignment"][b], M, N), perms[0], perms[1])
         out["la_err"] = float((got_la - S).abs().max())
-        torch.testing.assert_close(got_la, S, rtol=2e-5, atol=5e-4)
+        # an entry is 2 sim_ij - lse_row - lse_col + ...: four terms of the magnitude of the largest similarity, each good to a few ulps
+        # of it (256-term dot products in another summation order).  The seeded stress weights (final_proj = 8 I) push |sim| to ~4e2,
+        # where one fp32 ulp is 3e-5; with moderate weights (|sim| ~ 50) the bound is 7e-4.
+        sim_max = float(ref["_sim"].abs().max()) if "_sim" in ref else 0.0
+        torch.testing.assert_close(got_la, S, rtol=2e-5, atol=5e-4 + 32 * 1.2e-7 * sim_max)
         eps = max(2 * out["la_err"], la_floor)
     out["eps_la"] = eps
     out["m0"] = check_matches(p["matches0"][b, :M], ref["matches0"][0], S, th, eps, perms[0], perms[1])
