@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmatchglue.so")
-SOURCES = ["api.hip", "gemm.hip", "conv.hip", "conv_f16.hip", "gemm_f16.hip", "attention_f16.hip", "sg_misc.hip", "nn_misc.hip", "gs_misc.hip", "sp_post.hip", "attention.hip", "lg_misc.hip", "ffn_f16.hip", "wf_misc.hip"]
+SOURCES = ["api.hip", "gemm.hip", "conv.hip", "conv_f16.hip", "gemm_f16.hip", "attention_f16.hip", "sg_misc.hip", "nn_misc.hip", "gs_misc.hip", "sp_post.hip", "attention.hip", "lg_misc.hip", "ffn_f16.hip", "wf_misc.hip", "heads_f16.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 
 

@@ -935,20 +935,29 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
         }
         continue;
     }
-    {
-        ProfScope ps(h, s, "sp.convPb");
-        if (f16) {
-            GemmF16Args g = lin_args_f16(h->convPb, cP, 256, (int)n8);
-            g.C = lg; g.ldc = ldl; g.N = ldl;
-            launch_gemm_f16x3(g, s);
-        } else {
-            GemmArgs g = lin_args(h->convPb, cP, 256, (int)n8, lg, 65);
-            launch_gemm(g, s);
+    static const bool unfused_heads = getenv("MG_HEADS_UNFUSED") != nullptr;  // A/B timing of the three-launch form only
+    if (f16 && !unfused_heads && !h->taps.count("sp.logits")) {
+        ProfScope ps(h, s, "sp.heads");  // convPb + soft-max + depth-to-space (heads_f16.hip)
+        HeadsF16Args a;
+        a.in = cP; a.W = h->convPb.Wh; a.Npad = h->convPb.Npad; a.bias = h->convPb.bias; a.post_scale = h->convPb.ps; a.post_shift = h->convPb.pt;
+        a.heat = heat; a.B = B; a.hc = hc; a.wc = wc;
+        launch_heads_f16x3(a, s);
+    } else {
+        {
+            ProfScope ps(h, s, "sp.convPb");
+            if (f16) {
+                GemmF16Args g = lin_args_f16(h->convPb, cP, 256, (int)n8);
+                g.C = lg; g.ldc = ldl; g.N = ldl;
+                launch_gemm_f16x3(g, s);
+            } else {
+                GemmArgs g = lin_args(h->convPb, cP, 256, (int)n8, lg, 65);
+                launch_gemm(g, s);
+            }
         }
-    }
-    {
-        ProfScope ps(h, s, "sp.softmax_d2s");
-        launch_softmax_d2s(lg, ldl, B, hc, wc, heat, s);
+        {
+            ProfScope ps(h, s, "sp.softmax_d2s");
+            launch_softmax_d2s(lg, ldl, B, hc, wc, heat, s);
+        }
     }
     {
         ProfScope ps(h, s, "sp.convDb");

@@ -133,6 +133,19 @@ struct FfnF16Args {
 };
 void launch_ffn_f16x3(const FfnF16Args& a, hipStream_t s);
 
+// ---- heads_f16.hip : convPb + soft-max + depth-to-space in one kernel (f16x3 mode) ---------------------------------------
+struct HeadsF16Args {
+    const void* in = nullptr;    // SH8 (cells, 256): convPa output
+    const void* W = nullptr;     // SH8 tiled [256/16][Npad][64 B], rows 0..64 real
+    int Npad = 0;
+    const float* bias = nullptr;        // (>= 65)
+    const float* post_scale = nullptr;  // optional BatchNorm affine of the open variant (>= 65)
+    const float* post_shift = nullptr;
+    float* heat = nullptr;       // (B, 8 hc, 8 wc)
+    int B = 0, hc = 0, wc = 0;
+};
+void launch_heads_f16x3(const HeadsF16Args& a, hipStream_t s);
+
 // ---- sp_post.hip ---------------------------------------------------------------------------------
 void launch_softmax_d2s(const float* logits, int ld, int B, int hc, int wc, float* heat, hipStream_t s);
 void launch_l2norm_rows(float* x, long long rows, int dim, hipStream_t s);
