@@ -17,7 +17,7 @@ profiles/run_kernel_trace.sh "${tag}_f16x3" --steps 4 --warmup 2 > "$out/${tag}_
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
     timeout -k 10 500 rocprofv3 --pmc $c --kernel-trace --output-format csv -d "$out/pmc_${tag}_$c" -o pmc -- \
-        python3 "$root/bench.py" --no-cpu-baseline --steps 2 --warmup 1 > "$out/${tag}_pmc_$c.log" 2>&1
+        python3 "$root/bench.py" --no-cpu-baseline --no-f32 --steps 2 --warmup 1 > "$out/${tag}_pmc_$c.log" 2>&1
 done
 cd "$root"
 f=$(find "$out/pmc_${tag}_FETCH_SIZE" -name "*counter_collection.csv" | head -1)

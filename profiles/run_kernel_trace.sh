@@ -8,7 +8,7 @@ root=${GRAFT_REPO_ROOT:-$(pwd)}
 mkdir -p "$root/gpurun_out"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --kernel-trace --stats --output-format csv -d "$root/gpurun_out/prof_$tag" -o "$tag" -- \
-    python3 "$root/bench.py" --no-cpu-baseline "$@" > "$root/gpurun_out/${tag}_prof.log" 2>&1
+    python3 "$root/bench.py" --no-cpu-baseline --no-f32 "$@" > "$root/gpurun_out/${tag}_prof.log" 2>&1
 f=$(find "$root/gpurun_out/prof_$tag" -name "*kernel_stats.csv" | head -1)
 python3 - "$f" "$root/gpurun_out/${tag}_kernel_stats.csv" <<'PY'
 import csv, sys

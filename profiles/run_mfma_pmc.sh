@@ -7,7 +7,7 @@ out="$root/gpurun_out"
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 timeout -k 10 500 rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d "$out/pmc_${tag}_mfma" -o pmc -- \
-    python3 "$root/bench.py" --no-cpu-baseline --steps 2 --warmup 1 > "$out/${tag}_pmc_mfma.log" 2>&1
+    python3 "$root/bench.py" --no-cpu-baseline --no-f32 --steps 2 --warmup 1 > "$out/${tag}_pmc_mfma.log" 2>&1
 cd "$root"
 f=$(find "$out/pmc_${tag}_mfma" -name "*counter_collection.csv" | head -1)
 head -2 "$f" | cut -c1-600
