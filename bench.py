@@ -96,6 +96,9 @@ def algorithmic_flops(B):
         "sp.convPb": 2.0 * 256 * 65 * hw[3] * n, "sp.convDb": 2.0 * 256 * 256 * hw[3] * n,
         "lg.gemm.qkv": lin(256, 768), "lg.gemm.qkv_cross": lin(256, 512), "lg.gemm.out": lin(256, 256),
         "lg.gemm.ffn0": lin(512, 512), "lg.gemm.ffn3": lin(512, 256), "lg.gemm.final_proj": lin(256, 256),
+        "lg.ffn": lin(512, 512) + lin(512, 256),  # ffn.0 + ffn.3 in one launch (csrc/ffn_f16.hip)
+        "sp.heads": 2.0 * 256 * 65 * hw[3] * n,    # convPb inside the fused detector head (csrc/heads_f16.hip)
+        "sg.ffn": lin(512, 512) + lin(512, 256), "gs.ffn": lin(512, 512) + lin(512, 256),
         "lg.gemm.sim": 2.0 * B * K * K * 256,
         # attention contractions: 2*h*Nq*Nk*dh each; self = QK^T + PV on both images;
         # cross = one shared similarity + two PV products (the reference computes sim once, lightglue.py:201)
