@@ -14,6 +14,8 @@
 // A workgroup is 8 waves (16x32 or 32x16 pixels x 64 channels), one per CU with two waves per SIMD:
 // one 83 KB LDS stage, the next chunk prefetched into registers while the current one is multiplied.
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 #include "kernels.h"
@@ -21,6 +23,8 @@
 namespace {
 
 constexpr int CT = 512;  // threads per workgroup of the 8-wave arrangements
+#define PIN() __builtin_amdgcn_sched_barrier(0)
+constexpr int CONV_DMA_MAXC = 512;  // conv3x3_dma_kernel keeps the bias of the whole layer in LDS
 
 // Phase ablations used for the numbers in DESIGN.md: compile this file with -DCONV_ABL=<n> into a second library and
 // run bench.py with MG_LIB_PATH pointing at it (same box, same clocks).  7 = epilogue without its stores (results are
@@ -405,6 +409,310 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
     }
 }
 
+// ---- round 2: the same convolution with LDS-DMA staging -----------------------------------------------------------
+// The kernel above stops all eight waves twice per 16-channel chunk (barrier, ds_write of the staged registers,
+// barrier).  Here nothing passes through registers: a STAGE is one filter row of one chunk (3 taps x 12 MFMAs per wave),
+//   * the halo tile of a chunk (46 / 52 KB) is double-buffered and fetched by global_load_lds one chunk ahead
+//     (all of it is issued during the first stage of the previous chunk);
+//   * the 3 x 64 x 64 B weight rows of a stage (12 KB) go through a four-slot ring, fetched three stages ahead;
+//   * one raw s_barrier per stage, nothing between it and the first MFMA (its fragments were read under the previous
+//     tap), one filler per MFMA: the eight fragment reads of the next tap into the other register set, then the DMA
+//     pieces this wave owes the ring.
+// vmcnt retires in order, so "everything issued up to the stage before last has landed" is one counted s_waitcnt; to
+// keep that count exact every DMA and every output store is executed unconditionally, through buffer instructions: a
+// halo lane outside the image gets an offset past num_records and the bounds check returns zeros into LDS, an output
+// lane outside the image is dropped the same way (no exec-mask branches that could skip a VMEM instruction).  Each
+// wave issues the same number of halo pieces (pieces of LP <= 64 lanes); the twelve weight pieces of a stage are
+// issued by waves 0-3 (one per SIMD), so the counts are compile-time constants per wave class.
+template <int N>
+__device__ __forceinline__ void wait_vm_c() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer-resource builtins exist in the device pass only (the host pass needs just the kernel stubs)
+struct BufStore {  // out-of-range lanes get an offset past num_records: the store is dropped, the instruction still issues
+    __amdgpu_buffer_rsrc_t r;
+    __device__ __forceinline__ void operator()(int idx, bool ok, u32x4 v) const {
+        __builtin_amdgcn_raw_buffer_store_b128(v, r, ok ? idx * 16 : (int)0x80000000, 0, 0);
+    }
+};
+
+// ReLU (+ 2x2 max-pool) + SH8 stores of one wave tile through a store functor (idx = 16-byte piece inside the image)
+template <bool POOL, class Store>
+__device__ __forceinline__ void epilogue_sh8_st(f32x16 (&acc)[2][2], const Store& st, int H, int W, int Cout, int yw, int xw, int n0, int lane) {
+    const int i32 = lane & 31, h = lane >> 5, ql = i32 & 3, blk = i32 >> 2;
+    const int c4 = Cout >> 2;
+    const int Ho = POOL ? H >> 1 : H, Wo = POOL ? W >> 1 : W;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int ch0 = n0 + mt * 32 + 16 * h;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = fmaxf(acc[mt][nt][r], 0.f);
+                if (POOL) {
+                    x = fmaxf(x, dpp_quad_xor1(x));
+                    x = fmaxf(x, dpp_quad_xor2(x));
+                }
+                v[r] = x;
+            }
+            half_swap8(v);
+            f16x8 hi0, lo0, hi1, lo1;
+            split8(f32x8{v[0], v[1], v[2], v[3], v[8], v[9], v[10], v[11]}, hi0, lo0);
+            split8(f32x8{v[4], v[5], v[6], v[7], v[12], v[13], v[14], v[15]}, hi1, lo1);
+            u32x4 q0 = __builtin_bit_cast(u32x4, hi0), q1 = __builtin_bit_cast(u32x4, lo0);
+            u32x4 q2 = __builtin_bit_cast(u32x4, hi1), q3 = __builtin_bit_cast(u32x4, lo1);
+            if (POOL) {
+                const int oy = (yw >> 1) + nt, ox = (xw >> 1) + blk;
+                st((oy * Wo + ox) * c4 + (ch0 >> 2) + ql, oy < Ho && ox < Wo && ch0 < Cout, quad_pick(q0, q1, q2, q3, ql));
+            } else {
+                quad_transpose(q0, q1, q2, q3, ql);
+#pragma unroll
+                for (int sidx = 0; sidx < 4; ++sidx) {
+                    const int oy = yw + 2 * nt + (sidx >> 1), ox = xw + 2 * blk + (sidx & 1);
+                    st((oy * Wo + ox) * c4 + (ch0 >> 2) + ql, oy < Ho && ox < Wo && ch0 < Cout, sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3);
+                }
+            }
+        }
+    }
+}
+
+#endif
+template <int WY, int WX, bool POOL>
+__global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WY * WX == 8, "eight waves");
+    constexpr int TH = 4 * WY, TW = 16 * WX;
+    constexpr int PW = ((TW + 2 + 7) / 16) * 16 + 8;            // pixel pitch == 8 (mod 16)
+    constexpr int NSLOT = ((TH + 1) * PW + TW + 2) * 4;         // 16-byte slots of a halo tile (last row without its pitch padding)
+    constexpr int NIW = (NSLOT + 511) / 512;                    // halo DMA pieces per wave
+    constexpr int LP = (NSLOT + 8 * NIW - 1) / (8 * NIW);       // lanes (16-byte slots) per halo piece
+    constexpr int IN_SZ = 8 * NIW * LP;
+    constexpr int WS = 3 * 64 * 4, WR = 4;                      // weight stage: 3 taps x 64 couts x 4 pieces = 12 DMA pieces of 1 KB
+    constexpr int NWA = 3;                                      // ... three per wave of class A (waves 0-3)
+    constexpr int E = POOL ? 4 : 16;                            // output stores per wave and item
+    static_assert(LP <= 64 && NIW + NWA <= 12 && NIW + NWA + E < 64, "filler slots / vmcnt range");
+    // ONE LDS array (see gemm_f16.hip): [2 halo tiles][4 weight stages][bias of the layer]
+    __shared__ u32x4 s_all[2 * IN_SZ + WR * WS + CONV_DMA_MAXC / 4];
+    u32x4* const s_in = s_all;
+    u32x4* const s_w = s_all + 2 * IN_SZ;
+    float* const s_bias = reinterpret_cast<float*>(s_all + 2 * IN_SZ + WR * WS);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(t >> 6);
+    const bool cls_a = wu < 4;
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int tiles = tiles_x * tiles_y, nslices = (p.Cout + 63) / 64;
+    const int total = tiles * nslices * p.B;
+    const int cin4 = p.Cin >> 2, nchunks = p.Cin >> 4;
+    const u32x4* in = reinterpret_cast<const u32x4*>(p.in);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wt), 0, 0x7fffffff, 0x00020000);
+
+    struct Item { int b, y0, x0, n0; };
+    auto item_of = [&](int id) {
+        int logical = id;
+        if ((total & 7) == 0) logical = (id & 7) * (total >> 3) + (id >> 3);
+        const int slice = logical % nslices, r = logical / nslices;
+        const int tile = r % tiles;
+        return Item{r / tiles, (tile / tiles_x) * TH, (tile % tiles_x) * TW, slice * 64};
+    };
+
+    for (int i = t; i < CONV_DMA_MAXC; i += 512) s_bias[i] = i < p.Cout ? p.bias[i] : 0.f;
+
+    // DMA geometry of this lane: halo piece j = wu + 8 i covers LDS slots [LP j, LP j + LP); slot g -> halo pixel P = g >> 2,
+    // stored piece g & 3 = source piece ^ ((P >> 2) & 3) (the DMA writes LDS linearly, so the swizzle goes on the source)
+    int in_off[NIW], in_yx[NIW], vo[NIW];
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+        const int g = (wu + 8 * i) * LP + lane, P = g >> 2, py = P / PW, px = P - py * PW;
+        const bool valid = g < NSLOT && px < TW + 2;
+        in_off[i] = ((py * p.W + px) * cin4 + ((g & 3) ^ ((P >> 2) & 3))) * 16;  // bytes from the tile's halo origin
+        in_yx[i] = valid ? (py << 16 | px) : -1;
+    }
+    auto set_vo = [&](const Item& it) {  // byte offsets of this lane's halo slots for item `it` (outside the image: out of range -> zeros)
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) {
+            const int py = in_yx[i] >> 16, px = in_yx[i] & 0xffff;
+            const bool ok = in_yx[i] >= 0 && (unsigned)(it.y0 + py - 1) < (unsigned)p.H && (unsigned)(it.x0 + px - 1) < (unsigned)p.W;
+            vo[i] = ok ? in_off[i] : (int)0x80000000;
+        }
+    };
+    int w_off[NWA];  // class A: weight pieces 3 wu .. 3 wu + 2 of a stage
+#pragma unroll
+    for (int i = 0; i < NWA; ++i) {
+        const int j = ((wu & 3) * NWA + i), tl = j >> 2, n = ((j & 3) * 64 + lane) >> 2;
+        w_off[i] = ((tl * p.CoutPad + n) * 4 + ((lane & 3) ^ ((n >> 2) & 3))) * 16;
+    }
+    auto in_rsrc = [&](const Item& it, int c) {  // base = halo origin of the tile (may lie before the image: those lanes are out of range)
+        const u32x4* base = in + (((long long)it.b * p.H + (it.y0 - 1)) * p.W + (it.x0 - 1)) * cin4 + c * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(base), 0, 0x7fffffff, 0x00020000);
+    };
+    auto dma_in = [&](const __amdgpu_buffer_rsrc_t& rs, int buf, int i) {
+        if (lane < LP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, s_in + buf * IN_SZ + (wu + 8 * i) * LP, 16, vo[i], 0, 0, 0);
+    };
+    auto dma_w = [&](int n0, int c, int ky, int slot, int i) {
+        const int soff = (((c * 9 + 3 * ky) * p.CoutPad + n0) * 4) * 16;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, s_w + slot * WS + ((wu & 3) * NWA + i) * 64, 16, w_off[i], soff, 0, 0);
+    };
+
+    const int wy0 = (wu / WX) * 4, wx0 = (wu % WX) * 16;
+    const int i32 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+    // pixel operand: lane n -> pixel (dy,dx) = ((n>>1)&1, n&1) of 2x2 block n>>2 (blocks along x).  PW = 8 (mod 16): the swizzle
+    // term of pixel P0 + ky PW + kx is that of P0 + kx with bit 1 flipped for odd ky, and the second pixel tile (+2 PW) has the same
+    const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
+    int b_hi[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) b_hi[kx] = (P0 + kx) * 4 + ((2 * h) ^ (((P0 + kx) >> 2) & 3));
+    const int a_hi = i32 * 4 + ((2 * h) ^ ((i32 >> 2) & 3));
+
+    f16x8 fr[2][8];  // [register set][ah0, bh0, bh1, ah1, bl0, bl1, al0, al1] in the order the MFMAs need them
+    auto read_frag = [&](int set, int buf, int slot, int ky, int kx, int i) {
+        const f16x8* si = reinterpret_cast<const f16x8*>(s_in + buf * IN_SZ) + ky * PW * 4;
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w + slot * WS) + kx * 64 * 4;
+        const int bx = b_hi[kx] ^ ((ky & 1) << 1);
+        switch (i) {
+            case 0: fr[set][0] = sw[a_hi]; break;
+            case 1: fr[set][1] = si[bx]; break;
+            case 2: fr[set][2] = si[bx + 2 * PW * 4]; break;
+            case 3: fr[set][3] = sw[a_hi + 32 * 4]; break;
+            case 4: fr[set][4] = si[bx ^ 1]; break;
+            case 5: fr[set][5] = si[(bx ^ 1) + 2 * PW * 4]; break;
+            case 6: fr[set][6] = sw[a_hi ^ 1]; break;
+            default: fr[set][7] = sw[(a_hi ^ 1) + 32 * 4]; break;
+        }
+    };
+
+    int id = blockIdx.x;
+    if (id >= total) return;
+    Item cur = item_of(id);
+    // prologue: halo tile of chunk 0 -> buffer 0, weight stages 0..2 -> slots 0..2
+    set_vo(cur);
+    {
+        const __amdgpu_buffer_rsrc_t rs = in_rsrc(cur, 0);
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) dma_in(rs, 0, i);
+        if (cls_a) {
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+                for (int i = 0; i < NWA; ++i) dma_w(cur.n0, 0, ky, ky, i);
+        }
+    }
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_frag(0, 0, 0, 0, 0, i);
+
+    int sidx = 0;                  // stage counter of the stream (ring slot = sidx & 3)
+    bool e_now = false, e_prev = false;  // an epilogue (E stores) was issued just before the current / the previous stage
+    for (;;) {
+        const bool more = id + (int)gridDim.x < total;
+        const Item nxt = item_of(more ? id + (int)gridDim.x : id);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        // one chunk = three stages; PAR = chunk parity = halo buffer, and tap T of the chunk uses register set (T + PAR) & 1
+        auto chunk = [&](auto par_c, int c) {
+            constexpr int PAR = decltype(par_c)::value;
+            const bool last = c + 1 == nchunks;
+            const bool has_next = !last || more;      // the chunk after this one exists
+            const Item& nit = last ? nxt : cur;
+            const int nc = last ? 0 : c + 1;
+            if (last) set_vo(nxt);                    // the halo tile fetched during this chunk belongs to the next item
+            const __amdgpu_buffer_rsrc_t rs = in_rsrc(nit, nc);
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                // my DMA pieces up to the stage before last have landed (VMEM issued since: the previous stage's pieces and,
+                // around an item boundary, the E output stores), then everyone's
+                if (ky == 0) {        // previous stage = last stage of the previous chunk (NWA pieces in class A)
+                    if (e_now) { if (cls_a) wait_vm_c<NWA + E>(); else wait_vm_c<E>(); }
+                    else { if (cls_a) wait_vm_c<NWA>(); else wait_vm_c<0>(); }
+                } else if (!has_next) {
+                    wait_vm_c<0>();
+                } else if (ky == 1) { // previous stage issued the weight pieces and the whole next halo tile
+                    if (e_prev) { if (cls_a) wait_vm_c<NWA + NIW + E>(); else wait_vm_c<NIW + E>(); }
+                    else { if (cls_a) wait_vm_c<NWA + NIW>(); else wait_vm_c<NIW>(); }
+                } else {
+                    if (cls_a) wait_vm_c<NWA>(); else wait_vm_c<0>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                e_prev = e_now;
+                e_now = false;
+                const int slot = sidx & 3, slot1 = (sidx + 1) & 3, slot3 = (sidx + 3) & 3;
+                int dslot = 0;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int T = 3 * ky + kx, S = (T + PAR) & 1;
+                    int fslot = 0;
+                    auto filler = [&]() {
+                        const int f = fslot++;
+                        if (f < 8) {  // fragment read f of the next tap -> the other register set
+                            if (T < 8) read_frag(1 - S, PAR, kx == 2 ? slot1 : slot, (T + 1) / 3, (T + 1) % 3, f);
+                            else read_frag(1 - S, 1 - PAR, slot1, 0, 0, f);
+                        } else {      // DMA: the weight rows three stages ahead (class A), then (first stage of a chunk) the next halo tile
+                            const int d = dslot++;
+                            if (has_next) {
+                                if (d < NWA) { if (cls_a) dma_w(nit.n0, nc, ky, slot3, d); }
+                                else if (ky == 0 && d - NWA < NIW) dma_in(rs, 1 - PAR, d - NWA);
+                            }
+                        }
+                        PIN();
+                    };
+                    PIN();
+                    acc[0][0] = mfma16(fr[S][0], fr[S][1], acc[0][0]); filler();
+                    acc[0][1] = mfma16(fr[S][0], fr[S][2], acc[0][1]); filler();
+                    acc[1][0] = mfma16(fr[S][3], fr[S][1], acc[1][0]); filler();
+                    acc[1][1] = mfma16(fr[S][3], fr[S][2], acc[1][1]); filler();
+                    acc[0][0] = mfma16(fr[S][0], fr[S][4], acc[0][0]); filler();
+                    acc[0][1] = mfma16(fr[S][0], fr[S][5], acc[0][1]); filler();
+                    acc[1][0] = mfma16(fr[S][3], fr[S][4], acc[1][0]); filler();
+                    acc[1][1] = mfma16(fr[S][3], fr[S][5], acc[1][1]); filler();
+                    acc[0][0] = mfma16(fr[S][6], fr[S][1], acc[0][0]); filler();
+                    acc[0][1] = mfma16(fr[S][6], fr[S][2], acc[0][1]); filler();
+                    acc[1][0] = mfma16(fr[S][7], fr[S][1], acc[1][0]); filler();
+                    acc[1][1] = mfma16(fr[S][7], fr[S][2], acc[1][1]); filler();
+                }
+                ++sidx;
+            }
+        };
+#pragma unroll 1
+        for (int c = 0; c < nchunks; c += 2) {
+            chunk(std::integral_constant<int, 0>{}, c);
+            chunk(std::integral_constant<int, 1>{}, c + 1);
+        }
+        // epilogue: bias (LDS table of the whole layer), ReLU, pool, SH8 -- E unconditional buffer stores per wave
+        {
+            const float* sb = s_bias + cur.n0;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + mt * 32 + 8 * j + 4 * h);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc[mt][nt][4 * j] += bv[0]; acc[mt][nt][4 * j + 1] += bv[1];
+                        acc[mt][nt][4 * j + 2] += bv[2]; acc[mt][nt][4 * j + 3] += bv[3];
+                    }
+                }
+            const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+            const int img_bytes = Ho * Wo * p.Cout * 4;
+            BufStore st{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)cur.b * img_bytes, 0, img_bytes, 0x00020000)};
+            epilogue_sh8_st<POOL>(acc, st, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, cur.n0, lane);
+            e_now = true;
+        }
+        if (!more) break;
+        cur = nxt;
+        id += gridDim.x;
+    }
+#endif
+}
+
 // conv1a + conv1b + 2x2 max-pool in one kernel (superpoint.py:209-211): the 64-channel full-resolution
 // map of conv1a (78.6 MB per VGA image) never exists in HBM.  Per 16-channel chunk the conv1a outputs of
 // the 18x34 halo tile are recomputed from a 20x36 gray tile in LDS (VALU, weights in SGPRs: every wave
@@ -692,11 +1000,30 @@ void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
     };
     const long long w42 = waste(16, 32), w81 = waste(32, 16);
     const int nslices = (a.Cout + 63) / 64;
+    const long long w22 = waste(8, 32);
     // fewest wasted tile pixels wins; on a tie the 4-wave 8x32 tile (two workgroups per CU, whose
     // staging / epilogue phases overlap each other's MFMA phases) is preferred -- measured 7-11 % faster
     // than one 8-wave workgroup per CU on the 240x320 and 120x160 maps.
-    const long long w22 = waste(8, 32);
     const bool generic = !(a.relu && !a.out_f32 && !a.post_scale);  // BatchNorm affine / fp32 output / no ReLU
+    // Hot layout (ReLU, SH8 out): the LDS-DMA kernel, 16x32 or 32x16 pixel tiles, one 8-wave workgroup per CU.
+    // MG_CONV_STAGED=1 keeps the register-staged kernel below for A/B timing.
+    const char* env_staged = getenv("MG_CONV_STAGED");
+    const bool staged_only = env_staged && env_staged[0] == '1';
+    const long long out_img_bytes = (long long)(a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W) * a.Cout * 4;
+    if (!generic && !staged_only && a.Cin % 32 == 0 && a.Cout % 4 == 0 && a.Cout <= CONV_DMA_MAXC && out_img_bytes < (1ll << 31) &&
+        (!a.pool || (a.H % 2 == 0 && a.W % 2 == 0))) {
+        const bool wide = w42 <= w81;
+        const long long items = (wide ? (long long)((a.H + 15) / 16) * ((a.W + 31) / 32) : (long long)((a.H + 31) / 32) * ((a.W + 15) / 16)) * nslices * a.B;
+        const dim3 grid((unsigned)std::min<long long>(items, cu_count()));
+        if (wide) {
+            if (a.pool) hipLaunchKernelGGL((conv3x3_dma_kernel<4, 2, true>), grid, dim3(CT), 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_dma_kernel<4, 2, false>), grid, dim3(CT), 0, s, a);
+        } else {
+            if (a.pool) hipLaunchKernelGGL((conv3x3_dma_kernel<8, 1, true>), grid, dim3(CT), 0, s, a);
+            else hipLaunchKernelGGL((conv3x3_dma_kernel<8, 1, false>), grid, dim3(CT), 0, s, a);
+        }
+        return;
+    }
     // persistent grid: as many workgroups as fit on the chip at once (LDS: two 4-wave, one 8-wave per CU)
     auto grid_for = [&](long long items, int per_cu) { return dim3((unsigned)std::min<long long>(items, (long long)cu_count() * per_cu)); };
     if (w22 <= w42 && w22 <= w81) {
