@@ -139,6 +139,7 @@ struct mg_context {
     std::map<std::string, size_t> tap_count;
 
     bool profile = false;
+    std::string prof_filter;  // when not empty only the scope of that name is timed (mg_profile_filter)
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
     size_t event_used = 0;
@@ -165,7 +166,7 @@ struct ProfScope {
     hipStream_t s;
     size_t idx = 0;
     bool on;
-    ProfScope(mg_context* h_, hipStream_t s_, const char* name) : h(h_), s(s_), on(h_->profile) {
+    ProfScope(mg_context* h_, hipStream_t s_, const char* name) : h(h_), s(s_), on(h_->profile && (h_->prof_filter.empty() || h_->prof_filter == name)) {
         if (!on) return;
         ProfEntry e;
         e.name = name;
@@ -809,6 +810,12 @@ int mg_profile_enable(mg_handle h, int on) {
     h->profile = on != 0;
     h->prof.clear();
     h->event_used = 0;
+    return 0;
+}
+
+int mg_profile_filter(mg_handle h, const char* name) {
+    if (!h) return fail(MG_ERR_ARG, "handle is NULL");
+    h->prof_filter = name ? name : "";
     return 0;
 }
 

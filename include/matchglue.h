@@ -65,7 +65,7 @@ int mg_create(int device, mg_handle* out);
 int mg_destroy(mg_handle h);
 const char* mg_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
-#define MG_ABI_VERSION 8 /* bumped whenever an entry point or a conf struct changes */
+#define MG_ABI_VERSION 9 /* bumped whenever an entry point or a conf struct changes */
 int mg_abi_version(void);   /* == MG_ABI_VERSION of the header the library was built from */
 
 /* -- arithmetic ------------------------------------------------------------------------------
@@ -219,6 +219,9 @@ int mg_debug_read(mg_handle h, const char* tap, float* dst, size_t capacity, siz
  * when enabled: mg_profile_enable(h,1); after a forward + stream sync, mg_profile_read() fills
  * names/ms for up to `cap` entries and returns the number available.                          */
 int mg_profile_enable(mg_handle h, int on);
+/* Restrict the timing to the one scope called `name` (NULL or "" = all scopes again).  An event pair costs about
+ * 10 us of stream time per launch, so a throughput measurement times only the kernel its roofline is quoted on.  */
+int mg_profile_filter(mg_handle h, const char* name);
 int mg_profile_read(mg_handle h, char (*names)[48], float* ms, int cap);
 
 /* Stand-alone self-test entries of the two matrix cores, in the arithmetic mode set by mg_set_precision()
