@@ -24,9 +24,12 @@
 
 namespace {
 
-constexpr int TN = 256, TM = 256, BK = 16, GT = 512;  // 8 waves: 2 (features) x 4 (tokens), each 128 x 64
-constexpr int RS = 3;                                  // ring slots per operand: stage k+3 is issued into the slot stage k just left
+constexpr int TN = 256, BK = 16;  // 2 (feature halves) x TOKW (token groups) waves, each 128 features x 64 tokens
+constexpr int RS = 3;             // ring slots per operand: stage k+3 is issued into the slot stage k just left
 constexpr int TSLOTS = RS, WSLOTS = RS;
+// TOKW = 4: 256 x 256 tile, 8 waves, 99 KB of LDS, one workgroup per CU.  TOKW = 2: 256 features x 128 tokens, 4 waves, 75 KB,
+// TWO workgroups per CU: with K = 256-512 the loop is short and load / MFMA / epilogue of one tile run back to back, so
+// the second workgroup's loop fills the first one's epilogue (VALU + stores) and vice versa.
 #define PIN() __builtin_amdgcn_sched_barrier(0)
 
 __device__ __forceinline__ int swz(int row, int q) { return row * 4 + (q ^ ((row >> 2) & 3)); }  // 64-byte rows
@@ -48,8 +51,10 @@ __device__ __attribute__((noinline)) void epilogue_ragged(const GemmF16Args& p, 
     }
 }
 
-template <bool W_ROWMAJOR, bool RAGGED>
-__global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
+template <bool W_ROWMAJOR, bool RAGGED, int TOKW>
+__global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
+    constexpr int TM = 64 * TOKW, GT = 128 * TOKW;
+    constexpr int NWP = 16 / (2 * TOKW), NPW = 2 + NWP;  // weight pieces / all DMA pieces per wave and stage (token pieces: always 2)
     // ONE LDS array (a second __shared__ object next to LDS-DMA staging makes hipcc drain vmcnt before
     // every fragment read): [token ring: TSLOTS x 256 rows x 64 B][weight ring: WSLOTS x 256 rows x 64 B] = 144 KB
     __shared__ u32x4 s_ring[(TSLOTS * TM + WSLOTS * TN) * 4 + 3 * TN / 4];  // + bias | post_scale | post_shift of this feature tile
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
     float* const s_par = reinterpret_cast<float*>(s_ring + (TSLOTS * TM + WSLOTS * TN) * 4);
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-    const int wf = wave >> 2, wt = wave & 3;
+    const int wf = wave / TOKW, wt = wave % TOKW;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so the
     // feature tiles of one token tile are given ids 8 apart -- same XCD, adjacent in time.
     const int nft = (p.N + TN - 1) / TN, ntt = (p.M + TM - 1) / TM;
@@ -87,14 +92,18 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
     // A stage is one 16-deep k-step: 256 token rows x 64 B + 256 feature rows x 64 B, moved to LDS by LDS-DMA
     // (global_load_lds_dwordx4: no VGPR round trip, no ds_write; the DMA writes LDS linearly, so the XOR swizzle is applied
     // to the per-lane SOURCE piece; rows past the edge are clamped, their outputs are never stored).  32 pieces of 1 KB per
-    // stage: every wave issues two token pieces (2 wu, 2 wu + 1) and two weight pieces.
+    // stage: every wave issues two token pieces (2 wu, 2 wu + 1) and NWP weight pieces.
     long long tok_off[2];
-    long long w_off[2];
+    long long w_off[NWP];
 #pragma unroll
     for (int j = 0; j < 2; ++j) {
         const int slot = (wu * 2 + j) * 64 + lane, row = slot >> 2, q = (slot & 3) ^ ((row >> 2) & 3);
         tok_off[j] = (long long)min(m0 + row, p.M - 1);  // row index; the row stride depends on the source (A0 / A1)
         tok_off[j] = tok_off[j] * 4 + q;                 // packed: row * 4 + piece (lda is applied per stage)
+    }
+#pragma unroll
+    for (int j = 0; j < NWP; ++j) {
+        const int slot = (wu * NWP + j) * 64 + lane, row = slot >> 2, q = (slot & 3) ^ ((row >> 2) & 3);
         if (W_ROWMAJOR) w_off[j] = (long long)min(n0 + row, p.N - 1) * 4 + q;
         else w_off[j] = (long long)(n0 + row) * 4 + q;
     }
@@ -112,12 +121,14 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
         const u32x4* src;
         if (W_ROWMAJOR) src = Wg + (((w_off[j] >> 2) * p.ldw + k0) >> 2) + (w_off[j] & 3);
         else src = Wg + (long long)(k0 >> 4) * p.Npad * 4 + w_off[j];
-        __builtin_amdgcn_global_load_lds(src, s_wr + (kt % RS) * TN * 4 + (wu * 2 + j) * 64, 16, 0, 0);
+        __builtin_amdgcn_global_load_lds(src, s_wr + (kt % RS) * TN * 4 + (wu * NWP + j) * 64, 16, 0, 0);
     };
     const int npro = min(RS, nk);
 #pragma unroll 1
     for (int s0 = 0; s0 < npro; ++s0) {
-        dma_tok(s0, 0); dma_tok(s0, 1); dma_w(s0, 0); dma_w(s0, 1);
+        dma_tok(s0, 0); dma_tok(s0, 1);
+#pragma unroll
+        for (int j = 0; j < NWP; ++j) dma_w(s0, j);
     }
     // per-feature epilogue parameters -> LDS (one global round trip per workgroup, under the DMA prologue)
     for (int i = t; i < TN; i += GT) {
@@ -137,9 +148,9 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
         else al[set][i - 8] = sw[lane_lo + (i - 8) * 32 * 4];
     };
     if (nk > 0 && !(p.debug & 2)) {
-        // stage 0 landed (mine): all but the younger stages' pieces (4 per stage)
-        if (npro >= 3) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-        else if (npro == 2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        // stage 0 landed (mine): all but the younger stages' pieces (NPW per stage)
+        if (npro >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
+        else if (npro == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -151,7 +162,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
     // the four DMA pieces of stage kt+3, then the twelve fragment reads of stage kt+1 into the other register set
     auto stage = [&](auto set_c, int kt) {
         constexpr int S = decltype(set_c)::value;
-        if (kt + 2 <= nk - 1) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        if (kt + 2 <= nk - 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
         else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
@@ -159,8 +170,8 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
         int slot_i = 0;
         auto filler = [&]() {
             const int f = slot_i++ - 2;
-            if (f >= 0 && f < 4) { if (more_dma) { if (f < 2) dma_tok(kt + RS, f); else dma_w(kt + RS, f - 2); } }
-            else if (f >= 4 && f < 16) { if (more_rd) read_frag(1 - S, kt + 1, f - 4); }
+            if (f >= 0 && f < NPW) { if (more_dma) { if (f < 2) dma_tok(kt + RS, f); else dma_w(kt + RS, f - 2); } }
+            else if (f >= NPW && f < NPW + 12) { if (more_rd) read_frag(1 - S, kt + 1, f - NPW); }
             PIN();
         };
         PIN();
@@ -192,7 +203,7 @@ __global__ __launch_bounds__(GT, 2) void gemm_f16x3_kernel(const GemmF16Args p) 
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> inline-asm permlane reads
     __builtin_amdgcn_s_barrier();                         // s_par visible (also when the k-loop was empty)
     float* C = p.C ? p.C + z * p.strideC : nullptr;
-    const int wfu = wu >> 2;
+    const int wfu = wu / TOKW;
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
         const int fbase = n0 + wfu * 128 + ft * 32;  // uniform
@@ -332,16 +343,27 @@ void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
     static const int dbg = getenv("MG_GEMM_DEBUG") ? atoi(getenv("MG_GEMM_DEBUG")) : 0;  // timing experiments only
     GemmF16Args a = a0;
     a.debug = dbg;
+    // two 4-wave workgroups per CU (TOKW = 2) unless the problem is too small to give every CU two tiles anyway;
+    // MG_GEMM_TOKW=4 forces the 8-wave tile for A/B timing
+    static const int force_tokw = getenv("MG_GEMM_TOKW") ? atoi(getenv("MG_GEMM_TOKW")) : 0;
+    const int tokw = force_tokw == 4 ? 4 : 2;
+    const int TM = 64 * tokw;
     const int ntt = (a.M + TM - 1) / TM, nft = (a.N + TN - 1) / TN;
     dim3 grid(((ntt + 7) / 8) * 8 * nft, 1, a.batch);
     const bool ragged = (a.N & 31) != 0;
+#define MG_GEMM_LAUNCH(RM, RG)                                                                                      \
+    do {                                                                                                            \
+        if (tokw == 4) hipLaunchKernelGGL((gemm_f16x3_kernel<RM, RG, 4>), grid, dim3(512), 0, s, a);                  \
+        else hipLaunchKernelGGL((gemm_f16x3_kernel<RM, RG, 2>), grid, dim3(256), 0, s, a);                            \
+    } while (0)
     if (a.w_rowmajor) {
-        if (ragged) hipLaunchKernelGGL((gemm_f16x3_kernel<true, true>), grid, dim3(GT), 0, s, a);
-        else hipLaunchKernelGGL((gemm_f16x3_kernel<true, false>), grid, dim3(GT), 0, s, a);
+        if (ragged) MG_GEMM_LAUNCH(true, true);
+        else MG_GEMM_LAUNCH(true, false);
     } else {
-        if (ragged) hipLaunchKernelGGL((gemm_f16x3_kernel<false, true>), grid, dim3(GT), 0, s, a);
-        else hipLaunchKernelGGL((gemm_f16x3_kernel<false, false>), grid, dim3(GT), 0, s, a);
+        if (ragged) MG_GEMM_LAUNCH(false, true);
+        else MG_GEMM_LAUNCH(false, false);
     }
+#undef MG_GEMM_LAUNCH
 }
 
 void launch_to_sh8(const float* in, void* out, long long elems, float scale, hipStream_t s) {
