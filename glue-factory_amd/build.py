@@ -14,7 +14,18 @@ CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmatchglue.so")
 SOURCES = ["api.hip", "gemm.hip", "conv.hip", "conv_f16.hip", "gemm_f16.hip", "attention_f16.hip", "sg_misc.hip", "nn_misc.hip", "gs_misc.hip", "sp_post.hip", "attention.hip", "lg_misc.hip", "ffn_f16.hip", "wf_misc.hip", "heads_f16.hip"]
+# -packed-fp32-ops: no compiler-generated v_pk_*_f32.  On gfx950 a packed-fp32 instruction that broadcasts an operand half through
+# op_sel / op_sel_hi returned wrong low halves, nondeterministically, while MFMAs were executing on the same SIMD (conv_f16.hip:
+# conv1ab_dma_kernel, tests/test_gpu_determinism.py); the one place that wants packed FMAs writes them as inline asm on real pairs.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
+# conv_f16.hip keeps the instructions (the assembler rejects inline-asm v_pk_fma_f32 once the feature is off); instead its
+# device assembly is checked below: no packed-fp32 instruction with an op_sel / op_sel_hi modifier may appear.
+PK_CHECKED = {"conv_f16.hip"}
+# ffn_f16.hip keeps compiler-generated packed fp32 as well (without it the LayerNorm / GELU phase costs 0.8 ms per step): one
+# workgroup per CU, and its VALU phases with operand broadcasts run behind workgroup barriers, after every wave's MFMAs have retired
+PK_ALLOWED = {"ffn_f16.hip"}
+_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)"  # the host pass of every file says this
 
 
 def _stale():
@@ -37,13 +48,14 @@ def build(force=False, verbose=True):
     for src in SOURCES:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *([] if src in PK_CHECKED or src in PK_ALLOWED else NO_PK), "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
+        out = "\n".join(l for l in out.splitlines() if _NOISE not in l)
         if out.strip() and verbose:
             print(out)
         if p.returncode != 0:
@@ -51,6 +63,13 @@ def build(force=False, verbose=True):
             print(f"hipcc failed on {src}", file=sys.stderr)
     if failed:
         raise RuntimeError("libmatchglue build failed")
+    import re
+    for src in PK_CHECKED:
+        asm = subprocess.run([hipcc, *FLAGS, "-S", "--cuda-device-only", os.path.join(CSRC, src), "-o", "-"], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, text=True).stdout
+        bad = [l.strip() for l in asm.splitlines() if re.search(r"v_pk_[a-z]+_f32", l) and "op_sel" in l]
+        if bad:
+            raise RuntimeError(f"{src}: packed-fp32 instructions with an op_sel broadcast (unsafe beside MFMAs on gfx950): {bad[:3]} ...")
     cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
     if verbose:
         print(" ".join(cmd), flush=True)

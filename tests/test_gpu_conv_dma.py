@@ -1,5 +1,6 @@
-"""The LDS-DMA 3x3 convolution (conv3x3_dma_kernel) against the register-staged kernel it replaces: same MFMA order,
-so every encoder layer must be BIT-identical (SH8 words), on interior, border and ragged tiles, pooled and not."""
+"""The LDS-DMA convolutions (conv1ab_dma_kernel, conv3x3_dma_kernel) against the register-staged kernels they replace: same
+accumulation orders, so every encoder layer must be BIT-identical (SH8 words), on interior, border and ragged tiles, pooled
+and not, gray and RGB input, one and several tiles per workgroup."""
 import os
 
 import pytest
@@ -21,6 +22,7 @@ def run_layers(img, dev, staged):
         os.environ["MG_CONV_STAGED"] = "1"
     else:
         os.environ.pop("MG_CONV_STAGED", None)
+        os.environ["MG_CONV1AB_DMA"] = "1"   # the opt-in fused conv1a + conv1b kernel on the same stage machinery
     try:
         m = get_model("gluefactory_amd.superpoint")({"max_num_keypoints": 16, "nms_radius": 3, "detection_threshold": 0.0, "precision": "f16x3",
                                                       "force_num_keypoints": True, "dense_outputs": True}).eval()
@@ -40,14 +42,15 @@ def run_layers(img, dev, staged):
         return out
     finally:
         os.environ.pop("MG_CONV_STAGED", None)
+        os.environ.pop("MG_CONV1AB_DMA", None)
 
 
-@pytest.mark.parametrize("shape", [(2, 480, 640), (3, 64, 96), (1, 136, 200), (2, 248, 72), (5, 120, 168)])
+@pytest.mark.parametrize("shape", [(2, 480, 640, 1), (3, 64, 96, 3), (1, 136, 200, 1), (2, 248, 72, 3), (5, 120, 168, 1), (9, 240, 320, 3)])
 def test_dma_conv_bit_identical_to_staged(shape):
     dev = torch.device("cuda:0")
-    B, H, W = shape
+    B, H, W, C = shape
     g = torch.Generator().manual_seed(H * 7 + W)
-    img = F.avg_pool2d(torch.rand(B, 1, H + 4, W + 4, generator=g), 5, 1)
+    img = F.avg_pool2d(torch.rand(B, C, H + 4, W + 4, generator=g), 5, 1)
     img = (img - img.amin()) / (img.amax() - img.amin())
     a = run_layers(img, dev, staged=True)
     b = run_layers(img, dev, staged=False)
