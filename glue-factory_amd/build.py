@@ -17,7 +17,12 @@ SOURCES = ["api.hip", "gemm.hip", "conv.hip", "conv_f16.hip", "gemm_f16.hip", "a
 # -packed-fp32-ops: no compiler-generated v_pk_*_f32.  On gfx950 a packed-fp32 instruction that broadcasts an operand half through
 # op_sel / op_sel_hi returned wrong low halves, nondeterministically, while MFMAs were executing on the same SIMD (conv_f16.hip:
 # conv1ab_dma_kernel, tests/test_gpu_determinism.py); the one place that wants packed FMAs writes them as inline asm on real pairs.
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+# -fma-mix-insts: no v_fma_mix*.  With scalar multiplies hipcc turned `(_Float16)(x * s)` into v_fma_mixlo_f16 (ONE rounding of the
+# exact product) next to a separately rounded fp32 product: the hi half written by split8 and the hi half its lo was computed
+# against then differed in the double-rounding cases, an error of one fp16 ulp (2^-11) in a value that should carry 22 bits
+# (to_sh8_kernel; caught by tests/test_gpu_f16x3_range.py).
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
+         "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
 NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # conv_f16.hip keeps the instructions (the assembler rejects inline-asm v_pk_fma_f32 once the feature is off); instead its
 # device assembly is checked below: no packed-fp32 instruction with an op_sel / op_sel_hi modifier may appear.
@@ -25,7 +30,7 @@ PK_CHECKED = {"conv_f16.hip"}
 # ffn_f16.hip keeps compiler-generated packed fp32 as well (without it the LayerNorm / GELU phase costs 0.8 ms per step): one
 # workgroup per CU, and its VALU phases with operand broadcasts run behind workgroup barriers, after every wave's MFMAs have retired
 PK_ALLOWED = {"ffn_f16.hip"}
-_NOISE = "'-packed-fp32-ops' is not a recognized feature for this target (ignoring feature)"  # the host pass of every file says this
+_NOISE = "is not a recognized feature for this target (ignoring feature)"  # the host pass of every file says this about both features
 
 
 def _stale():

@@ -16,6 +16,8 @@ import sys
 SHORT = {
     "conv1ab_f16x3_kernel": "sp.conv1ab",
     "conv3x3_f16x3_kernel": "sp.conv3x3",
+    "conv3x3_dma_kernel": "sp.conv3x3",
+    "conv1ab_dma_kernel": "sp.conv1ab",
     "gemm_f16x3_kernel<false": "gemm (tiled weights)",
     "gemm_f16x3_kernel<true": "lg.gemm.sim",
     "attention_f16x3_kernel": "lg.attn",
