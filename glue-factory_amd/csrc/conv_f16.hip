@@ -574,18 +574,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
     const int a_hi = i32 * 4 + ((2 * h) ^ ((i32 >> 2) & 3));
 
     f16x8 fr[2][8];  // [register set][ah0, bh0, bh1, ah1, bl0, bl1, al0, al1] in the order the MFMAs need them
-#pragma unroll
-    for (int i = 0; i < 16; ++i) fr[i >> 3][i & 7] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     auto read_frag = [&](int set, int buf, int slot, int ky, int kx, int i) {
         const f16x8* si = reinterpret_cast<const f16x8*>(s_in + buf * IN_SZ) + ky * PW * 4;
         const f16x8* sw = reinterpret_cast<const f16x8*>(s_w + slot * WS) + kx * 64 * 4;
         const int bx = b_hi[kx] ^ ((ky & 1) << 1);
-        // The old fragment stays "in use" until the very instruction that refills it: a register of a fragment whose last MFMA
-        // has been issued is otherwise handed to the VALU work between the MFMAs, and a VALU result (or an LDS return) written
-        // into a source register of an MFMA that has been issued but not yet executed corrupts that MFMA (seen on hardware:
-        // nondeterministic outputs; a refill at least seven MFMAs later is safe).
-        const int ix = i < 7 ? i : 7;
-        asm volatile("" ::"v"(fr[set][ix]));
         switch (i) {
             case 0: fr[set][0] = sw[a_hi]; break;
             case 1: fr[set][1] = si[bx]; break;
@@ -946,9 +938,9 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
 //   * the weight rows of conv1b go through the same four-slot LDS-DMA ring, one barrier per filter row -- the two barriers
 //     and the register -> LDS weight copy per chunk are gone;
 //   * all eight waves multiply all the time; the conv1a outputs of the NEXT chunk (three halo pixels x eight channels per
-//     lane) are computed in fifteen small steps (per pixel: four of two taps, one of the last tap + bias / ReLU / split /
-//     LDS write) placed as fillers between the MFMAs of the first two stages of a chunk, so they are in LDS one stage
-//     before the fragment prefetch of the next chunk needs them;
+//     lane) are computed in twelve small steps (nine taps of the three pixels, three of bias / ReLU / split / LDS write)
+//     placed as fillers between the MFMAs of the first two stages of a chunk, every third MFMA, so they are in LDS one
+//     stage before the fragment prefetch of the next chunk needs them;
 //   * the gray tile of the next image tile is fetched during chunk 0 (six unconditional buffer loads per thread: a
 //     one-channel image is read three times so that the VMEM count does not depend on C), converted and stored into
 //     the second gray buffer during chunk 1, and used by the produce steps of chunk 3.
@@ -1032,29 +1024,34 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
     // invariants were spilled -- and a scratch reload is a VMEM instruction, which would break the counted vmcnt waits) and
     // (ii) sinking all nine taps of a pixel into the guarded store block of its last step (one 130-instruction VALU block
     // between two MFMAs with every tap's weights preloaded into registers).
-    f32x2 o2[4];
-    f32x4 tw0[2], tw1[2];
-    f32x2 tg2[2];  // gray value of a tap as the register pair {g, g}: one ds_read2_b32 with both offsets equal (no VALU, no op_sel)
+    f32x2 o2[3][4];           // three pixels x eight channels (as four register pairs each)
+    f32x4 tw0[2], tw1[2];     // table row of a tap (this wave's eight channels): [tap parity]
+    f32x2 tg2[2][3];          // gray value of a tap as the register pair {g, g}, per pixel: [tap parity][pixel]
     int c1v = gg * 8;  // this wave's channel offset inside a chunk, held in a VGPR so that the constants fold into ds_read offsets
     asm volatile("" : "+v"(c1v));
-    auto p_issue = [&](int st, int chn, int gb) {  // LDS reads for step st
-        const int i = st / 5, q = st % 5;
-        int go = gofs[i];
-        asm volatile("" : "+v"(go));
-        // the gray pairs first: these asm loads are not tracked by the compiler's s_waitcnt insertion, but LDS returns in order and
-        // every FMA also needs a table row requested AFTER them, which the compiler does wait for
-        const unsigned ga = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(s_g + gb * GSZ + go);
+    // step k (0..9) requests the LDS operands of tap k (k == 9: the bias row): one table row serves the three pixels, so the
+    // conv1a phase reads 18 table rows + 27 gray pairs per chunk and wave (per-pixel steps read the table three times: at 256 B/clk
+    // the LDS then runs at ~85 % with the MFMA fragments and the produce stores)
+    unsigned ga[3];  // LDS byte addresses of the three pixels' gray windows, set at the first step of a chunk
+    auto p_issue = [&](int k, int chn, int gb) {
+        const int set = k & 1;
+        if (k == 0) {
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int k = 2 * q + e;
-            if (k < 9) asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%2" : "=v"(tg2[e]) : "v"(ga), "n"((k / 3) * GP + (k % 3)));
+            for (int i = 0; i < 3; ++i) {
+                int go = gofs[i];
+                asm volatile("" : "+v"(go));  // computed here, once per chunk: not hoisted out of the tile loop for all chunks / gray buffers
+                ga[i] = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(s_g + gb * GSZ + go);
+            }
         }
+        if (k < 9) {
+            // the gray pairs first: these asm loads are not tracked by the compiler's s_waitcnt insertion, but LDS returns in order
+            // and every FMA also needs the table row requested AFTER them, which the compiler does wait for
 #pragma unroll
-        for (int e = 0; e < 2; ++e) {
-            const int k = 2 * q + e;  // tap; for q == 4 the second slot holds the bias
-            tw0[e] = *reinterpret_cast<const f32x4*>(&s_c1[k * 64 + chn * 16 + c1v]);
-            tw1[e] = *reinterpret_cast<const f32x4*>(&s_c1[k * 64 + chn * 16 + c1v + 4]);
+            for (int i = 0; i < 3; ++i)
+                asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%2" : "=v"(tg2[set][i]) : "v"(ga[i]), "n"((k / 3) * GP + (k % 3)));
         }
+        tw0[set] = *reinterpret_cast<const f32x4*>(&s_c1[k * 64 + chn * 16 + c1v]);
+        tw1[set] = *reinterpret_cast<const f32x4*>(&s_c1[k * 64 + chn * 16 + c1v + 4]);
     };
     // Same tap order and the same IEEE fma as the reference accumulation; v_pk_fma_f32 = two fmas per instruction.  The whole
     // library is compiled WITHOUT hipcc's packed-fp32 code generation (build.py: -packed-fp32-ops): packed-fp32 instructions whose
@@ -1062,18 +1059,21 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
     // {g, g}) returned wrong LOW halves, nondeterministically, whenever MFMAs were executing on the same SIMD -- here between this
     // wave's own MFMAs (even conv1a channels wrong, never in the MFMA-free prologue, not cured by nops or waits), and in the GEMM
     // epilogue once a second workgroup's MFMAs shared the SIMD (tests/test_gpu_determinism.py, tests/micro/diag_conv1ab_det.py).
-    // Packed FMAs on REAL register pairs, no op_sel, are clean (same tests), so these are written out as inline asm.
+    // Packed FMAs on REAL register pairs, no op_sel, are clean (same tests), so these are written out as inline asm -- which also
+    // keeps hipcc from sinking all taps into the guarded store block of the last step.
     const f32x2 zero2 = {0.f, 0.f};
-    auto p_fma = [&](int e, bool first) {
-        const f32x2 g2 = tg2[e];
-        const f32x2 w[4] = {f32x2{tw0[e][0], tw0[e][1]}, f32x2{tw0[e][2], tw0[e][3]}, f32x2{tw1[e][0], tw1[e][1]}, f32x2{tw1[e][2], tw1[e][3]}};
+    auto p_tap = [&](int k) {
+        const int set = k & 1;
+        const f32x2 w[4] = {f32x2{tw0[set][0], tw0[set][1]}, f32x2{tw0[set][2], tw0[set][3]}, f32x2{tw1[set][0], tw1[set][1]}, f32x2{tw1[set][2], tw1[set][3]}};
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (first) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o2[k]) : "v"(w[k]), "v"(g2), "v"(zero2));
-            else asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(o2[k]) : "v"(w[k]), "v"(g2));
-        }
+        for (int i = 0; i < 3; ++i)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                if (k == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o2[i][c]) : "v"(w[c]), "v"(tg2[set][i]), "v"(zero2));
+                else asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(o2[i][c]) : "v"(w[c]), "v"(tg2[set][i]));
+            }
     };
-    auto p_fin = [&](int i, int buf, const Tile& tl) {  // bias (in tw0[1] | tw1[1]), ReLU, zero outside the image, SH8 pieces -> halo tile
+    auto p_fin = [&](int i, int buf, const Tile& tl) {  // bias (row 9 -> tw0[1] | tw1[1]), ReLU, zero outside the image, SH8 pieces -> halo tile
         int hp = hp0 + 256 * i;
         asm volatile("" : "+v"(hp));
         const int py = hp / (TW + 2), px = hp - py * (TW + 2);
@@ -1082,8 +1082,8 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
         f32x8 v;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            v[j] = inside ? fmaxf(o2[j >> 1][j & 1] + tw0[1][j], 0.f) : 0.f;
-            v[4 + j] = inside ? fmaxf(o2[2 + (j >> 1)][j & 1] + tw1[1][j], 0.f) : 0.f;
+            v[j] = inside ? fmaxf(o2[i][j >> 1][j & 1] + tw0[1][j], 0.f) : 0.f;
+            v[4 + j] = inside ? fmaxf(o2[i][2 + (j >> 1)][j & 1] + tw1[1][j], 0.f) : 0.f;
         }
         f16x8 hi, lo;
         split8(v, hi, lo);
@@ -1093,12 +1093,13 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
             s_in[buf * IN_SZ + P * 4 + ((2 * gg + 1) ^ sw4)] = __builtin_bit_cast(u32x4, lo);
         }
     };
-    auto p_step = [&](int st, int chn, int gb, int buf, const Tile& tl) {
-        const int q = st % 5;
-        p_fma(0, q == 0);
-        if (q < 4) p_fma(1, false);
-        if (q == 4) p_fin(st / 5, buf, tl);
-        if (st + 1 < 15) p_issue(st + 1, chn, gb);
+    // position 0: request tap 0; positions 1-9: multiply tap pos - 1 and request the next row (row 9 = bias); positions 10-12: finishes
+    auto p_step = [&](int pos, int chn, int gb, int buf, const Tile& tl) {
+        if (pos == 0) p_issue(0, chn, gb);
+        else if (pos <= 9) {
+            p_tap(pos - 1);
+            p_issue(pos, chn, gb);
+        } else if (pos <= 12) p_fin(pos - 10, buf, tl);
     };
 
     // class A: weight pieces 3 wu .. 3 wu + 2 of a stage.  Piece j = tap j >> 2, couts 16 (j & 3) + (lane >> 2): the lane term is one
@@ -1120,18 +1121,10 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
     const int a_hi = i32 * 4 + ((2 * h) ^ ((i32 >> 2) & 3));
 
     f16x8 fr[2][8];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) fr[i >> 3][i & 7] = f16x8{0, 0, 0, 0, 0, 0, 0, 0};
     auto read_frag = [&](int set, int buf, int slot, int ky, int kx, int i) {
         const f16x8* si = reinterpret_cast<const f16x8*>(s_in + buf * IN_SZ) + ky * PW * 4;
         const f16x8* sw = reinterpret_cast<const f16x8*>(s_w + slot * WS) + kx * 64 * 4;
         const int bx = b_hi[kx] ^ ((ky & 1) << 1);
-        // The old fragment stays "in use" until the very instruction that refills it: a register of a fragment whose last MFMA
-        // has been issued is otherwise handed to the VALU work between the MFMAs, and a VALU result (or an LDS return) written
-        // into a source register of an MFMA that has been issued but not yet executed corrupts that MFMA (seen on hardware:
-        // nondeterministic outputs; a refill at least seven MFMAs later is safe).
-        const int ix = i < 7 ? i : 7;
-        asm volatile("" ::"v"(fr[set][ix]));
         switch (i) {
             case 0: fr[set][0] = sw[a_hi]; break;
             case 1: fr[set][1] = si[bx]; break;
@@ -1163,9 +1156,8 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();  // gray tile, tap table, bias table
-    p_issue(0, 0, 0);
 #pragma unroll
-    for (int st = 0; st < 15; ++st) p_step(st, 0, 0, 0, cur);
+    for (int pos = 0; pos <= 12; ++pos) p_step(pos, 0, 0, 0, cur);
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
 #pragma unroll
@@ -1217,8 +1209,7 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
                     const int T = 3 * ky + kx, S = (T + PAR) & 1;
                     int fslot = 0;
                     // fillers of tap kx: slots 0-7 the fragment reads of the next tap; slots 2, 5, 8, 11 a conv1a step of the next chunk
-                    // (first two stages; position 0 only requests the operands of step 0, so every step finds its LDS operands
-                    // three MFMAs old); slots 9, 10 the VMEM work: weight pieces of the stage three ahead (class A: taps 0, 0, 1)
+                    // (first two stages; every step requests the LDS operands of the next one, so they are three MFMAs old when used); slots 9, 10 the VMEM work: weight pieces of the stage three ahead (class A: taps 0, 0, 1)
                     // and, in the third stage of chunk 0, the six gray-tile loads; the gray store in the third stage of chunk 1
                     auto filler = [&]() {
                         const int f = fslot++;
@@ -1228,10 +1219,7 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
                         }
                         if ((f == 2 || f == 5 || f == 8 || f == 11) && ky < 2) {
                             const int pos = ky * 12 + kx * 4 + (f - 2) / 3;
-                            if (has_next) {
-                                if (pos == 0) p_issue(0, NC, ngb);
-                                else if (pos <= 15) p_step(pos - 1, NC, ngb, 1 - PAR, ntl);
-                            }
+                            if (has_next && pos <= 12) p_step(pos, NC, ngb, 1 - PAR, ntl);
                         }
                         if (f == 9 || f == 10) {
                             const int d = kx * 2 + (f - 9);  // 0..5
@@ -1408,10 +1396,10 @@ void launch_conv1ab_f16x3(const ConvF16Args& a, const Conv1aArgs& c1, hipStream_
     const char* env_staged = getenv("MG_CONV_STAGED");
     const bool staged_only = env_staged && env_staged[0] == '1';
     const long long out_img_bytes = (long long)(a.H / 2) * (a.W / 2) * a.Cout * 4;
-    // conv1ab_dma_kernel (conv1a as fillers between the MFMAs, weights by LDS-DMA) is bit-identical to the register-staged kernel and
-    // measured at the same speed (4.21 ms per launch both, same box, profiles/r02_*): it stays opt-in (MG_CONV1AB_DMA=1, tested)
+    // conv1ab_dma_kernel (conv1a as fillers between the MFMAs, weights by LDS-DMA) is bit-identical to the register-staged kernel;
+    // MG_CONV1AB_DMA=0 selects the latter for A/B timing
     const char* env_dma = getenv("MG_CONV1AB_DMA");
-    const bool want_dma = env_dma && env_dma[0] == '1';
+    const bool want_dma = !(env_dma && env_dma[0] == '0');
     if (want_dma && !staged_only && !a.post_scale && !c1.post_scale && a.Cout == 64 && a.H % 2 == 0 && a.W % 2 == 0 && out_img_bytes < (1ll << 31) &&
         (long long)c1.C * c1.H * c1.W * 4 < (1ll << 31)) {
         hipLaunchKernelGGL(conv1ab_dma_kernel, grid, dim3(CT), 0, s, a, c1);

@@ -22,7 +22,6 @@ def run_layers(img, dev, staged):
         os.environ["MG_CONV_STAGED"] = "1"
     else:
         os.environ.pop("MG_CONV_STAGED", None)
-        os.environ["MG_CONV1AB_DMA"] = "1"   # the opt-in fused conv1a + conv1b kernel on the same stage machinery
     try:
         m = get_model("gluefactory_amd.superpoint")({"max_num_keypoints": 16, "nms_radius": 3, "detection_threshold": 0.0, "precision": "f16x3",
                                                       "force_num_keypoints": True, "dense_outputs": True}).eval()
@@ -42,7 +41,6 @@ def run_layers(img, dev, staged):
         return out
     finally:
         os.environ.pop("MG_CONV_STAGED", None)
-        os.environ.pop("MG_CONV1AB_DMA", None)
 
 
 @pytest.mark.parametrize("shape", [(2, 480, 640, 1), (3, 64, 96, 3), (1, 136, 200, 1), (2, 248, 72, 3), (5, 120, 168, 1), (9, 240, 320, 3)])
