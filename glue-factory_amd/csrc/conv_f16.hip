@@ -421,9 +421,9 @@ __global__ __launch_bounds__(64 * WY * WX, 2) void conv3x3_f16x3_kernel(const Co
 // vmcnt retires in order, so "everything issued up to the stage before last has landed" is one counted s_waitcnt; to
 // keep that count exact every DMA and every output store is executed unconditionally, through buffer instructions: a
 // halo lane outside the image gets an offset past num_records and the bounds check returns zeros into LDS, an output
-// lane outside the image is dropped the same way (no exec-mask branches that could skip a VMEM instruction).  Each
-// wave issues the same number of halo pieces (pieces of LP <= 64 lanes); the twelve weight pieces of a stage are
-// issued by waves 0-3 (one per SIMD), so the counts are compile-time constants per wave class.
+// lane outside the image is dropped the same way (no exec-mask branches that could skip a VMEM instruction).  Every
+// wave issues the same number of pieces: halo pieces of LP <= 64 lanes, weight pieces of 48 lanes (two per wave and stage: with
+// the twelve full pieces on waves 0-3 those four arrived late at every barrier), so the counts are compile-time constants.
 // lane id recomputed on the spot (volatile: never hoisted or kept live): for the once-per-tile code of a kernel at the register limit
 __device__ __forceinline__ int fresh_lane() {
     int l;
@@ -495,8 +495,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
     constexpr int NIW = (NSLOT + 511) / 512;                    // halo DMA pieces per wave
     constexpr int LP = (NSLOT + 8 * NIW - 1) / (8 * NIW);       // lanes (16-byte slots) per halo piece
     constexpr int IN_SZ = 8 * NIW * LP;
-    constexpr int WS = 3 * 64 * 4, WR = 4;                      // weight stage: 3 taps x 64 couts x 4 pieces = 12 DMA pieces of 1 KB
-    constexpr int NWA = 3;                                      // ... three per wave of class A (waves 0-3)
+    constexpr int WS = 3 * 64 * 4, WR = 4;                      // weight stage: 3 taps x 64 couts x 4 pieces = 768 slots of 16 B
+    constexpr int NWA = 2, WLP = WS / (8 * NWA);                // ... moved as two 48-lane pieces per wave (every wave issues the same VMEM count)
     constexpr int E = POOL ? 4 : 16;                            // output stores per wave and item
     static_assert(LP <= 64 && NIW + NWA <= 12 && NIW + NWA + E < 64, "filler slots / vmcnt range");
     // ONE LDS array (see gemm_f16.hip): [2 halo tiles][4 weight stages][bias of the layer]
@@ -507,7 +507,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
 
     const int t = threadIdx.x, lane = t & 63;
     const int wu = __builtin_amdgcn_readfirstlane(t >> 6);
-    const bool cls_a = wu < 4;
     const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
     const int tiles = tiles_x * tiles_y, nslices = (p.Cout + 63) / 64;
     const int total = tiles * nslices * p.B;
@@ -544,11 +543,11 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
             vo[i] = ok ? in_off[i] : (int)0x80000000;
         }
     };
-    int w_off[NWA];  // class A: weight pieces 3 wu .. 3 wu + 2 of a stage
+    int w_off[NWA];  // weight pieces NWA wu .. NWA wu + NWA - 1 of a stage: LDS slots [WLP j, WLP j + WLP)
 #pragma unroll
     for (int i = 0; i < NWA; ++i) {
-        const int j = ((wu & 3) * NWA + i), tl = j >> 2, n = ((j & 3) * 64 + lane) >> 2;
-        w_off[i] = ((tl * p.CoutPad + n) * 4 + ((lane & 3) ^ ((n >> 2) & 3))) * 16;
+        const int g = (wu * NWA + i) * WLP + min(lane, WLP - 1), row = g >> 2, tl = row >> 6, n = row & 63;
+        w_off[i] = ((tl * p.CoutPad + n) * 4 + ((g & 3) ^ ((n >> 2) & 3))) * 16;
     }
     auto in_rsrc = [&](const Item& it, int c) {  // base = halo origin of the tile (may lie before the image: those lanes are out of range)
         const u32x4* base = in + (((long long)it.b * p.H + (it.y0 - 1)) * p.W + (it.x0 - 1)) * cin4 + c * 4;
@@ -559,7 +558,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
     };
     auto dma_w = [&](int n0, int c, int ky, int slot, int i) {
         const int soff = (((c * 9 + 3 * ky) * p.CoutPad + n0) * 4) * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, s_w + slot * WS + ((wu & 3) * NWA + i) * 64, 16, w_off[i], soff, 0, 0);
+        if (lane < WLP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, s_w + slot * WS + (wu * NWA + i) * WLP, 16, w_off[i], soff, 0, 0);
     };
 
     const int wy0 = (wu / WX) * 4, wx0 = (wu % WX) * 16;
@@ -599,12 +598,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
         const __amdgpu_buffer_rsrc_t rs = in_rsrc(cur, 0);
 #pragma unroll
         for (int i = 0; i < NIW; ++i) dma_in(rs, 0, i);
-        if (cls_a) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int i = 0; i < NWA; ++i) dma_w(cur.n0, 0, ky, ky, i);
-        }
+            for (int i = 0; i < NWA; ++i) dma_w(cur.n0, 0, ky, ky, i);
     }
     asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
@@ -636,16 +633,14 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
             for (int ky = 0; ky < 3; ++ky) {
                 // my DMA pieces up to the stage before last have landed (VMEM issued since: the previous stage's pieces and,
                 // around an item boundary, the E output stores), then everyone's
-                if (ky == 0) {        // previous stage = last stage of the previous chunk (NWA pieces in class A)
-                    if (e_now) { if (cls_a) wait_vm_c<NWA + E>(); else wait_vm_c<E>(); }
-                    else { if (cls_a) wait_vm_c<NWA>(); else wait_vm_c<0>(); }
+                if (ky == 0) {        // previous stage = last stage of the previous chunk (its NWA weight pieces)
+                    if (e_now) wait_vm_c<NWA + E>(); else wait_vm_c<NWA>();
                 } else if (!has_next) {
                     wait_vm_c<0>();
                 } else if (ky == 1) { // previous stage issued the weight pieces and the whole next halo tile
-                    if (e_prev) { if (cls_a) wait_vm_c<NWA + NIW + E>(); else wait_vm_c<NIW + E>(); }
-                    else { if (cls_a) wait_vm_c<NWA + NIW>(); else wait_vm_c<NIW>(); }
+                    if (e_prev) wait_vm_c<NWA + NIW + E>(); else wait_vm_c<NWA + NIW>();
                 } else {
-                    if (cls_a) wait_vm_c<NWA>(); else wait_vm_c<0>();
+                    wait_vm_c<NWA>();
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -662,10 +657,10 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
                         if (f < 8) {  // fragment read f of the next tap -> the other register set
                             if (T < 8) read_frag(1 - S, PAR, kx == 2 ? slot1 : slot, (T + 1) / 3, (T + 1) % 3, f);
                             else read_frag(1 - S, 1 - PAR, slot1, 0, 0, f);
-                        } else {      // DMA: the weight rows three stages ahead (class A), then (first stage of a chunk) the next halo tile
+                        } else {      // DMA: the weight rows three stages ahead, then (first stage of a chunk) the next halo tile
                             const int d = dslot++;
                             if (has_next) {
-                                if (d < NWA) { if (cls_a) dma_w(nit.n0, nc, ky, slot3, d); }
+                                if (d < NWA) dma_w(nit.n0, nc, ky, slot3, d);
                                 else if (ky == 0 && d - NWA < NIW) dma_in(rs, 1 - PAR, d - NWA);
                             }
                         }
@@ -951,7 +946,7 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
     constexpr int PW = ((TW + 2 + 7) / 16) * 16 + 8;
     constexpr int NPIX = (TH + 2) * (TW + 2);
     constexpr int IN_SZ = (TH + 2) * PW * 4;
-    constexpr int WS = 3 * 64 * 4, WR = 4, NWA = 3;
+    constexpr int WS = 3 * 64 * 4, WR = 4, NWA = 2, WLP = WS / (8 * NWA);  // two 48-lane weight pieces per wave and stage
     constexpr int E = 4;                              // pooled output: four stores per wave and tile
     constexpr int NGL = 6;                            // gray-tile loads per thread and tile (2 pixels x 3 channels)
     constexpr int GH = TH + 4, GW = TW + 4, GP = GW + 1, GSZ = ((GH * GP + 3) / 4) * 4;
@@ -1102,13 +1097,15 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
         } else if (pos <= 12) p_fin(pos - 10, buf, tl);
     };
 
-    // class A: weight pieces 3 wu .. 3 wu + 2 of a stage.  Piece j = tap j >> 2, couts 16 (j & 3) + (lane >> 2): the lane term is one
-    // register, the rest is wave-uniform and goes into the scalar offset
-    const int w_lane = ((lane >> 2) * 4 + ((lane & 3) ^ ((lane >> 4) & 3))) * 16;
+    int w_off[NWA];  // weight pieces NWA wu .. NWA wu + NWA - 1 of a stage: LDS slots [WLP j, WLP j + WLP)
+#pragma unroll
+    for (int i = 0; i < NWA; ++i) {
+        const int g = (wu * NWA + i) * WLP + min(lane, WLP - 1), row = g >> 2, tl = row >> 6, n = row & 63;
+        w_off[i] = ((tl * p.CoutPad + n) * 4 + ((g & 3) ^ ((n >> 2) & 3))) * 16;
+    }
     auto dma_w = [&](int c, int ky, int slot, int i) {
-        const int j = (wu & 3) * NWA + i;
-        const int soff = (((c * 9 + 3 * ky + (j >> 2)) * p.CoutPad + (j & 3) * 16) * 4) * 16;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, s_w + slot * WS + j * 64, 16, w_lane, soff, 0, 0);
+        const int soff = (((c * 9 + 3 * ky) * p.CoutPad) * 4) * 16;
+        if (lane < WLP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, s_w + slot * WS + (wu * NWA + i) * WLP, 16, w_off[i], soff, 0, 0);
     };
 
     const int wy0 = (wu / WX) * 4, wx0 = (wu % WX) * 16;
@@ -1145,12 +1142,10 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
         const __amdgpu_buffer_rsrc_t rs = gray_rsrc(cur);
 #pragma unroll
         for (int j = 0; j < NGL; ++j) gray_load(rs, cur, j);
-        if ((wu < 4)) {
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky)
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-                for (int i = 0; i < NWA; ++i) dma_w(0, ky, ky, i);
-        }
+            for (int i = 0; i < NWA; ++i) dma_w(0, ky, ky, i);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread reads back what its own wave's DMA wrote
         gray_store(0);
     }
@@ -1188,16 +1183,15 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
                 // boundary, the E output stores), then everyone's
                 if (ky == 0) {
                     if (C == 1) {   // previous stage (0,2): weight pieces + the gray loads of the next tile
-                        if (more) { if ((wu < 4)) wait_vm_c<NWA + NGL>(); else wait_vm_c<NGL>(); }
-                        else { if ((wu < 4)) wait_vm_c<NWA>(); else wait_vm_c<0>(); }
-                    } else if (e_now) { if ((wu < 4)) wait_vm_c<NWA + E>(); else wait_vm_c<E>(); }
-                    else { if ((wu < 4)) wait_vm_c<NWA>(); else wait_vm_c<0>(); }
+                        if (more) wait_vm_c<NWA + NGL>(); else wait_vm_c<NWA>();
+                    } else if (e_now) wait_vm_c<NWA + E>();
+                    else wait_vm_c<NWA>();
                 } else if (!has_next) {
                     wait_vm_c<0>();
                 } else if (ky == 1 && e_prev) {
-                    if ((wu < 4)) wait_vm_c<NWA + E>(); else wait_vm_c<E>();
+                    wait_vm_c<NWA + E>();
                 } else {
-                    if ((wu < 4)) wait_vm_c<NWA>(); else wait_vm_c<0>();
+                    wait_vm_c<NWA>();
                 }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 __builtin_amdgcn_s_barrier();
@@ -1223,7 +1217,7 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
                         }
                         if (f == 9 || f == 10) {
                             const int d = kx * 2 + (f - 9);  // 0..5
-                            if (d < NWA && has_next && (wu < 4)) dma_w(NC, ky, slot3, d);
+                            if (d < NWA && has_next) dma_w(NC, ky, slot3, d);
                             if (C == 0 && ky == 2 && more) gray_load(rs_g, nxt, d);
                             if (C == 1 && ky == 2 && d == 0 && more) gray_store(gb ^ 1);
                         }
