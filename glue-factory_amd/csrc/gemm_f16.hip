@@ -62,6 +62,12 @@ __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16
     u32x4* const s_wr = s_ring + TSLOTS * TM * 4;
     float* const s_par = reinterpret_cast<float*>(s_ring + (TSLOTS * TM + WSLOTS * TN) * 4);
 
+    // Two workgroups share a CU (TOKW = 2).  Started together they stay in lockstep -- both in the K loop, then both in the
+    // epilogue: the phase ablation (MG_GEMM_DEBUG) shows loop, epilogue arithmetic and stores adding up to the launch time, nothing
+    // overlaps.  The workgroups the dispatcher places second on each CU (ids [CUs, 2 CUs) of the first round) therefore sleep about
+    // half a tile first; later workgroups inherit the offset from the slots they take over.
+    if ((int)blockIdx.x >= p.stagger_lo && (int)blockIdx.x < p.stagger_hi)
+        for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
     const int wf = wave / TOKW, wt = wave % TOKW;
     // XCD-aware tile order: workgroups are dealt round-robin over the 8 XCDs (private L2s), so the
@@ -347,6 +353,17 @@ void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
     // MG_GEMM_TOKW=4 forces the 8-wave tile for A/B timing
     static const int force_tokw = getenv("MG_GEMM_TOKW") ? atoi(getenv("MG_GEMM_TOKW")) : 0;
     const int tokw = force_tokw == 4 ? 4 : 2;
+    // sweep on one box (profiles/r02_z notes in DESIGN.md): 0 / 1 / 2 / 3 / 5 -> qkv 1.081 / 1.058 / 1.033 / 1.025 / 1.090 ms per step
+    static const int stagger = getenv("MG_GEMM_STAGGER") ? atoi(getenv("MG_GEMM_STAGGER")) : 3;
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    }
+    a.stagger = tokw == 2 ? stagger : 0;
+    a.stagger_lo = cus;
+    a.stagger_hi = 2 * cus;
     const int TM = 64 * tokw;
     const int ntt = (a.M + TM - 1) / TM, nft = (a.N + TN - 1) / TN;
     dim3 grid(((ntt + 7) / 8) * 8 * nft, 1, a.batch);

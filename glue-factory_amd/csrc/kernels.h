@@ -109,6 +109,7 @@ struct GemmF16Args {
     int batch = 1;
     long long strideA = 0, strideW = 0, strideC = 0, strideCs = 0;  // elements
     int debug = 0;  // timing experiments: 1 = skip the stores, 2 = skip the main loop
+    int stagger = 0, stagger_lo = 0, stagger_hi = 0;  // workgroups [lo, hi) sleep `stagger` x 8128 cycles before they start (set by the launcher)
 };
 void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s);
 void launch_to_sh8(const float* in, void* out, long long elems, float scale, hipStream_t s);  // SH8(in * scale)
