@@ -4,8 +4,15 @@ TEST INFRASTRUCTURE ONLY -- never imported by the product package
 (`glue-factory_amd/`).  Only `tests/`, `__graft_entry__.smoke()` and the
 `cpu_baseline` leg of `bench.py` may use it, and only as the checker.
 
-This is a functional restatement (fp32, PyTorch-CPU operators, no reference
-imports) of the reference's hot path:
+This is a functional restatement (PyTorch-CPU operators, no reference imports)
+of the reference's hot path.  It computes in the dtype of its inputs: fp32
+tensors give the reference's own CPU arithmetic (that is what the goldens pin);
+the same code fed float64 weights and inputs (`cast(..., torch.float64)`) is the
+fp64 ANCHOR of oracle/anchor.py -- the independent truth against which both the
+HIP path's and the fp32 CPU path's float errors are measured.  Integer decisions
+of a run (keypoint pixels, pruning / stopping) can be replayed into another run
+(`force_yx`, `replay`) so that floats of two dtypes are compared element by
+element on the same decisions.  Paths restated:
 
   * SuperPoint (MagicLeap layout)  /root/reference/gluefactory_nonfree/superpoint.py:202-350
   * SuperPoint-open                /root/reference/gluefactory/models/extractors/superpoint_open.py:123-217
@@ -29,6 +36,17 @@ import torch.nn.functional as F
 from torch.nn.attention import SDPBackend, sdpa_kernel
 
 GRAY_WEIGHTS = (0.299, 0.587, 0.114)
+
+
+def cast(obj, dtype):
+    """Recursively cast the floating tensors of a dict / list / tuple (weights, data dicts) to `dtype`."""
+    if isinstance(obj, torch.Tensor):
+        return obj.to(dtype) if obj.is_floating_point() else obj
+    if isinstance(obj, dict):
+        return {k: cast(v, dtype) for k, v in obj.items()}
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(cast(v, dtype) for v in obj)
+    return obj
 
 
 # --------------------------------------------------------------------------
@@ -124,7 +142,7 @@ def nms_heatmap(scores, radius):
     zero = torch.zeros_like(scores)
     keep = scores == pool(scores)
     for _ in range(2):
-        suppressed = pool(keep.float()) > 0
+        suppressed = pool(keep.to(scores.dtype)) > 0
         rest = torch.where(suppressed, zero, scores)
         fresh = rest == pool(rest)
         keep = keep | (fresh & ~suppressed)
@@ -207,26 +225,33 @@ SP_DEFAULTS = dict(
 )
 
 
-def superpoint_forward(data, W, **conf):
+def superpoint_forward(data, W, force_yx=None, dense=None, **conf):
     """Sparse SuperPoint forward.  Returns per-image lists plus stacked tensors when counts agree.
+
+    `force_yx`: per-image list of (n,2) int64 (y,x) pixels that replaces the detector's own selection (the scores are
+    read from this run's heat map at those pixels) -- used to evaluate the float outputs of another run's decisions.
+    `dense`: a (heatmap, dense descriptors) pair already computed by `sp_dense` for this input (skips the dense stage).
 
     Output keys: keypoints (x,y)+0.5, keypoint_scores, descriptors (K,256) per image;
     `heatmap`, `dense_descriptors` always returned for stage-wise checks.
     """
     cfg = {**SP_DEFAULTS, **conf}
     variant = cfg["variant"]
-    heat, dense = sp_dense(data["image"], W, variant)
+    heat, dense = sp_dense(data["image"], W, variant) if dense is None else dense
     s = nms_heatmap(heat, cfg["nms_radius"])
     s = mask_borders(s, cfg["remove_borders"], data.get("image_size"), honour_image_size=(variant == "magicleap"))
     k = cfg["max_num_keypoints"]
-    sel = select_keypoints(s, cfg["detection_threshold"], None if (k is None or k <= 0) else k)
+    if force_yx is not None:
+        sel = [(yx, heat[i][yx[:, 0], yx[:, 1]]) for i, yx in enumerate(force_yx)]  # the raw map: a forced pixel need not survive THIS run's NMS
+    else:
+        sel = select_keypoints(s, cfg["detection_threshold"], None if (k is None or k <= 0) else k)
     if variant == "open":
         mode = "open"
     else:
         mode = "legacy" if cfg["legacy_sampling"] else "fixed"
     kps, scs, descs = [], [], []
     for i, (yx, v) in enumerate(sel):
-        xy = torch.flip(yx, [1]).float()
+        xy = torch.flip(yx, [1]).to(heat.dtype)
         d = sample_descriptors(xy[None], dense[i:i + 1], mode)[0]
         kps.append(xy + 0.5)
         scs.append(v)
@@ -366,13 +391,15 @@ def lg_confidence_threshold(layer_index, n_layers):
     return float(min(1.0, max(0.0, 0.8 + 0.1 * math.exp(-4.0 * layer_index / n_layers))))
 
 
-def lightglue_forward(data, W, collect_layers=(), **conf):
+def lightglue_forward(data, W, collect_layers=(), replay=None, **conf):
     """lightglue.py:399-525.  With depth_confidence / width_confidence <= 0 (every shipped config) the plain 9-layer pass.
 
     width_confidence > 0 restates the point pruning of :480-497 / :541-549 / :500-508 (it runs in the reference; pinned by
     tests/golden/lightglue_adaptive.npz).  depth_confidence > 0 restates the early stopping of :474-479 / :551-560 with the
     thresholds of `confidence_threshold()`: the fork reads an undefined `self.confidence_thresholds` there and raises, so this
-    half follows the evident intent (= upstream LightGlue) and has no reference output to be pinned to.  Both need batch 1."""
+    half follows the evident intent (= upstream LightGlue) and has no reference output to be pinned to.  Both need batch 1.
+    `replay`: the `_decisions` list of another run (per layer: stop flag, kept indices of image 0 / 1); the adaptive decisions are
+    then taken from it instead of from this run's own confidences (fp64 anchor on the fp32 run's decisions)."""
     cfg = {**LG_DEFAULTS, **conf}
     k0, k1 = data["keypoints0"], data["keypoints1"]
     size0 = size1 = None
@@ -396,6 +423,7 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
     ind0, ind1 = torch.arange(m)[None], torch.arange(n)[None]
     prune0, prune1 = torch.ones_like(ind0), torch.ones_like(ind1)
     layers = {}
+    decisions = []
     last = L - 1
     for i in range(L):
         p = f"transformers.{i}"
@@ -414,9 +442,14 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
             tw, tb = W[f"token_confidence.{i}.token.0.weight"], W[f"token_confidence.{i}.token.0.bias"]
             t0, t1 = torch.sigmoid(F.linear(d0, tw, tb)).squeeze(-1), torch.sigmoid(F.linear(d1, tw, tb)).squeeze(-1)
             conf_all = torch.cat([t0, t1], -1)
-            if 1.0 - (conf_all < thr).float().sum() / (m + n) > cfg["depth_confidence"]:
+            stop = bool(1.0 - (conf_all < thr).float().sum() / (m + n) > cfg["depth_confidence"])
+            if replay is not None:
+                stop = replay[i][0]
+            if stop:
+                decisions.append((True, None, None))
                 last = i
                 break
+        dec = [False, None, None]
         if do_prune:  # :480-497
             mw, mb = W[f"log_assignment.{i}.matchability.weight"], W[f"log_assignment.{i}.matchability.bias"]
             for side in (0, 1):
@@ -425,12 +458,16 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
                 if t is not None:
                     keep = keep | (t <= thr)
                 kidx = torch.where(keep)[1]
+                if replay is not None:
+                    kidx = replay[i][1 + side]
+                dec[1 + side] = kidx
                 if side == 0:
                     ind0, d0, e0 = ind0.index_select(1, kidx), d0.index_select(1, kidx), e0.index_select(-2, kidx)
                     prune0[:, ind0] += 1
                 else:
                     ind1, d1, e1 = ind1.index_select(1, kidx), d1.index_select(1, kidx), e1.index_select(-2, kidx)
                     prune1[:, ind1] += 1
+        decisions.append(tuple(dec))
     S, sim = log_assignment(d0, d1, W, f"log_assignment.{last}")
     m0, m1, ms0, ms1, am0, am1 = filter_matches(S, cfg["filter_threshold"])
     if do_prune:  # :500-508
@@ -438,7 +475,7 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
         m1_ = torch.full((b, n), -1, dtype=m1.dtype)
         m0_[:, ind0] = torch.where(m0 == -1, -1, ind1.gather(1, m0.clamp(min=0)))
         m1_[:, ind1] = torch.where(m1 == -1, -1, ind0.gather(1, m1.clamp(min=0)))
-        s0_, s1_ = torch.zeros(b, m), torch.zeros(b, n)
+        s0_, s1_ = ms0.new_zeros(b, m), ms0.new_zeros(b, n)
         s0_[:, ind0] = ms0
         s1_[:, ind1] = ms1
         m0, m1, ms0, ms1 = m0_, m1_, s0_, s1_
@@ -459,6 +496,7 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
         "_sim": sim,
         "_layers": layers,
         "_layers_run": last + 1,
+        "_decisions": decisions,
         "_ind0": ind0,
         "_ind1": ind1,
     }
@@ -467,13 +505,16 @@ def lightglue_forward(data, W, collect_layers=(), **conf):
 # --------------------------------------------------------------------------
 # Two-view composite
 # --------------------------------------------------------------------------
-def two_view_forward(data, W_sp, W_lg, sp_conf, lg_conf, with_maps=False):
+def two_view_forward(data, W_sp, W_lg, sp_conf, lg_conf, with_maps=False, force_yx=None, dense=None):
     """two_view_pipeline.py:62-90 -- extractor per view, keys suffixed 0/1, then the matcher.
     `with_maps` also returns the score maps behind the keypoint decisions (`_nms_scores0/1`, `_heatmap0/1`) for
-    the tie-aware index checks of the tests; they are not part of the reference's pred dict."""
+    the tie-aware index checks of the tests; they are not part of the reference's pred dict.
+    `force_yx` = (list per image of view 0, list per image of view 1) of (n,2) (y,x) pixels, `dense` = (dense stage of view 0,
+    of view 1): see superpoint_forward."""
     pred, maps = {}, {}
     for i in ("0", "1"):
-        p = superpoint_forward(data["view" + i], W_sp, **sp_conf)
+        p = superpoint_forward(data["view" + i], W_sp, force_yx=None if force_yx is None else force_yx[int(i)],
+                               dense=None if dense is None else dense[int(i)], **sp_conf)
         for k in ("keypoints", "keypoint_scores", "descriptors"):
             pred[k + i] = p[k]
         if sp_conf.get("variant") == "open":

@@ -7,7 +7,8 @@ region is 1024x768 (`image_size`), 2048 keypoints.
 Two properties, no thresholds:
   * batch invariance: pair i inside the batch is BIT-IDENTICAL (every output tensor) to pair i run alone;
   * pairs {0, 15, 31} (configs[1]) / pair 7 (configs[2]) agree with the CPU oracle under the tie-aware exact rule of
-    tests/tie_aware.py (indices may differ only at proven near-ties of the oracle's own decisions), floats within 1e-4.
+    oracle/tie_aware.py (indices may differ only at proven near-ties of the oracle's own decisions), floats within 1e-4 of the
+    oracle run in float64 (oracle/anchor.py).
 Inputs: SURVEY 8(d)'s tiling of the boat pair with per-item circular shifts (tests/golden/two_view_boat.npz holds the images).
 """
 import os
@@ -17,6 +18,7 @@ import pytest
 import torch
 
 import tie_aware as TA
+from oracle import anchor as AN
 from oracle import sp_lg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -65,7 +67,10 @@ def run_case(dev, precision, B, H, W, Hv, K, oracle_pairs):
     for i in oracle_pairs:
         data = {"view0": {"image": im0[i:i + 1], "image_size": size[:1]}, "view1": {"image": im1[i:i + 1], "image_size": size[:1]}}
         ref = O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
-        r = TA.check_two_view(p, ref, i, K, 0.1, tag=f"{W}x{H} K{K} B{B} {precision}", score_atol=1e-4)  # moderate |sim|: the north-star tolerance itself
+        anchor = AN.TwoViewAnchor(data, W_sp, W_lg, spc, dict(filter_threshold=0.1))  # the oracle in float64: what 1e-4 is measured against
+        r = TA.check_two_view(p, ref, i, K, 0.1, tag=f"{W}x{H} K{K} B{B} {precision}", anchor=anchor)
+        # moderate |sim| (final_proj = 3 I): the fp32 CPU path is itself within 1e-4 of fp64, so the bound applied was north_star's 1e-4
+        assert all(v["bound"] == 1e-4 for k, v in r["floats"].items() if k != "log_assignment"), r["floats"]
         for s in ("0", "1"):
             rr = TA.check_keypoints(p["keypoints" + s][i], ref["keypoints" + s][0], ref["keypoint_scores" + s][0], ref["_nms_scores" + s][0],
                                     got_scores=p["keypoint_scores" + s][i], k_max=K)

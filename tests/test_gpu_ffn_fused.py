@@ -6,6 +6,7 @@ import pytest
 import torch
 
 import tie_aware as TA
+from oracle import anchor as AN
 from oracle import sp_lg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -50,9 +51,10 @@ def test_fused_ffn_equals_three_launch_form(B, M, N):
         print(f"B{B} M{M} N{N} {t}: max |fused - unfused| {err:.2e} (|x| max {tu[t].abs().max().item():.2f})")
         torch.testing.assert_close(tf[t], tu[t], rtol=0, atol=2e-5)
     assert torch.equal(pf["matches0"], pu["matches0"]) and torch.equal(pf["matches1"], pu["matches1"])
-    torch.testing.assert_close(pf["log_assignment"], pu["log_assignment"], rtol=2e-5, atol=2e-4)
     ref = O.lightglue_forward(data, W, filter_threshold=0.1)
-    torch.testing.assert_close(pf["ref_descriptors0"][:, 0], ref["ref_descriptors0"][:, 0], rtol=0, atol=1e-4)
+    # both forms against the float64 oracle: 1e-4, or 2 x the fp32 CPU path's own error where that exceeds 1e-4 (oracle/anchor.py)
+    _, r64 = AN.matcher_floats(O.lightglue_forward, pf, ref, data, W, f"fused B{B} M{M} N{N}", ("ref_descriptors0", "log_assignment"), dict(filter_threshold=0.1))
+    AN.matcher_floats(O.lightglue_forward, pu, ref, data, W, f"three-launch B{B} M{M} N{N}", ("ref_descriptors0", "log_assignment"), r64=r64)
     for b in range(B):
         eps = TA.la_eps(pf["log_assignment"][b], ref["log_assignment"][b])
         r = TA.check_matches(pf["matches0"][b], ref["matches0"][b], ref["log_assignment"][b], 0.1, eps)

@@ -1,10 +1,11 @@
 """Seeded random shapes through the whole native path against the oracle: odd image sizes (not multiples of the conv
-tiles), batch sizes 1-3, ragged keypoint counts, both SuperPoint layouts.  Floats within the north-star tolerance;
-keypoint indices / matches compared with the tie-aware exact rule of tests/tie_aware.py (no percentage thresholds)."""
+tiles), batch sizes 1-3, ragged keypoint counts, both SuperPoint layouts.  Floats within the north-star tolerance of the float64 oracle (oracle/anchor.py);
+keypoint indices / matches compared with the tie-aware exact rule of oracle/tie_aware.py (no percentage thresholds)."""
 import pytest
 import torch
 
 import tie_aware as TA
+from oracle import anchor as AN
 from oracle import sp_lg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -54,10 +55,11 @@ def test_two_view_random_shapes(dev, seed):
     for b in range(B):
         one = {"view0": {"image": img[b:b + 1], "image_size": size[:1]}, "view1": {"image": img[B + b:B + b + 1], "image_size": size[:1]}}
         ref = O.two_view_forward(one, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
+        anchor = AN.TwoViewAnchor(one, W_sp, W_lg, spc, dict(filter_threshold=0.1))
         counts = [ref["keypoints" + i].shape[1] for i in ("0", "1")]
         tag = f"seed {seed} B{B} {W}x{H} C{C} K{K} r{spc['nms_radius']} {variant}"
         if counts == [K, K]:
-            TA.check_two_view(p, ref, b, K, 0.1, tag=tag)
+            TA.check_two_view(p, ref, b, K, 0.1, tag=tag, anchor=anchor)
             n_full += 1
         else:
             # fewer than K detections: the batched rows are zero-padded (a documented difference from the reference's random
@@ -70,7 +72,7 @@ def test_two_view_random_shapes(dev, seed):
                 torch.testing.assert_close(p["descriptors" + i][b, :n][ok], ref["descriptors" + i][0][r["perm"][ok]], rtol=0, atol=ATOL)
             # ... and the pair alone (rows trimmed to the detected count, as the reference returns them) end to end
             q = {k: v.cpu() for k, v in solo(_to(one, dev)).items()}
-            TA.check_two_view(q, ref, 0, K, 0.1, tag=tag + " (alone)")
+            TA.check_two_view(q, ref, 0, K, 0.1, tag=tag + " (alone)", anchor=anchor)
         for i in ("0", "1"):
             n = counts[int(i)]
             torch.testing.assert_close(p["keypoint_scores" + i][b, :n].sort().values, ref["keypoint_scores" + i][0].sort().values, rtol=0, atol=ATOL)

@@ -1,8 +1,10 @@
-"""Stage-wise SuperPoint parity on the GPU: every encoder / head layer against the CPU oracle, both precisions."""
+"""Stage-wise SuperPoint parity on the GPU: every encoder / head layer against the CPU oracle, both precisions.  Activations reach
+|x| ~ 10: the bound is 1e-4 ABSOLUTE against the same stages evaluated in float64 (oracle/anchor.py), not a relative one."""
 import pytest
 import torch
 import torch.nn.functional as F
 
+from oracle import anchor as AN
 from oracle import sp_lg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -51,6 +53,7 @@ def test_encoder_layers_vs_oracle(precision, hw):
         eng.debug_request("sp." + n)
     m({"image": img.to(dev)})
     ref = oracle_stages(img, W)
+    ref64 = oracle_stages(img.double(), O.cast(W, torch.float64))
     worst = {}
     for n in names:
         r = ref[n].permute(0, 2, 3, 1).contiguous()  # NHWC
@@ -73,6 +76,5 @@ def test_encoder_layers_vs_oracle(precision, hw):
             for c in (0, 1, 4, 8, 17):
                 d = (rr[2, 3] - gg[2, 3, c]).abs()
                 print(n, f"got ch {c} at (2,3) closest ref ch {int(d.argmin())} err {d.min().item():.2e}")
+        AN.anchored_close(got, r, ref64[n].permute(0, 2, 3, 1), f"{precision} {hw} {n} (|x| max {worst[n][1]:.1f})")
     print(precision, hw, {k: f"{v[0]:.1e}" for k, v in worst.items()})
-    for n, (err, scale) in worst.items():
-        assert err <= 2e-5 * max(scale, 1.0), (n, err, scale)

@@ -9,6 +9,7 @@ import math
 import pytest
 import torch
 
+from oracle import anchor as AN
 from oracle import sp_lg_oracle as O
 
 pytestmark = pytest.mark.gpu
@@ -52,6 +53,7 @@ def test_superglue_golden(dev, golden, precision):
         B, M = data["keypoints0"].shape[:2]
         N = data["keypoints1"].shape[1]
         T = B * (M + N)
+        r64 = None
         for th in (0.0, 0.2):
             m = _module(dev, W, th, precision)
             eng = m.engine(dev)
@@ -63,8 +65,10 @@ def test_superglue_golden(dev, golden, precision):
                 r0, r1 = ref["_taps"][key]  # (B,256,K)
                 torch.testing.assert_close(x[: B * M].reshape(B, M, 256), r0.transpose(1, 2), rtol=0, atol=ATOL, msg=lambda s: f"{tag} {tap}: {s}")
                 torch.testing.assert_close(x[B * M:].reshape(B, N, 256), r1.transpose(1, 2), rtol=0, atol=ATOL, msg=lambda s: f"{tag} {tap}: {s}")
-            torch.testing.assert_close(p["sinkhorn_cost"].cpu(), g[tag + ".sinkhorn_cost"], rtol=1e-5, atol=ATOL)
-            torch.testing.assert_close(p["log_assignment"].cpu(), g[tag + ".log_assignment"], rtol=2e-5, atol=ATOL)
+            gold = {k: g[f"{tag}.{k}"] for k in ("sinkhorn_cost", "log_assignment")}
+            gold.update({k: g[f"{tag}.th{th}.{k}"] for k in ("matching_scores0", "matching_scores1")})
+            _, r64 = AN.matcher_floats(O.superglue_forward, p, gold, data, W, f"SG golden {tag} th{th} {precision}", ("sinkhorn_cost", "log_assignment"),
+                                       dict(filter_threshold=th), r64=r64)
             for k in ("matches0", "matches1"):
                 assert torch.equal(p[k].cpu(), g[f"{tag}.th{th}.{k}"]), (tag, th, k)
                 assert p[k].dtype == torch.int64
@@ -99,9 +103,10 @@ def test_superglue_vs_oracle_fullsize(dev, B, M, N, precision):
     agree = (p["matches0"].cpu() == ref["matches0"]).float().mean().item()
     print(f"[{precision}] B{B} M{M} N{N}: max|cost err| {cost_err:.2e} max|log_assignment err| {la_err:.2e} "
           f"matches0 agreement {agree:.5f} matched {(ref['matches0'] > -1).float().mean().item():.3f}")
-    torch.testing.assert_close(p["sinkhorn_cost"].cpu(), ref["sinkhorn_cost"], rtol=2e-5, atol=ATOL)
-    torch.testing.assert_close(p["log_assignment"].cpu(), ref["log_assignment"], rtol=2e-5, atol=5e-4)
-    # assignments identical except at proven near-ties of the oracle's own decision (tests/tie_aware.py); no percentage
+    # floats of both runs against the oracle in float64 (50 Sinkhorn iterations over |cost| ~ 1e2 entries: the fp32 CPU path is itself
+    # several 1e-4 from the exact value): 1e-4, or 2 x the CPU path's own error where that exceeds 1e-4 (oracle/anchor.py)
+    AN.matcher_floats(O.superglue_forward, p, ref, data, W, f"SG B{B} M{M} N{N} {precision}", ("sinkhorn_cost", "log_assignment"), dict(filter_threshold=0.2))
+    # assignments identical except at proven near-ties of the oracle's own decision (oracle/tie_aware.py); no percentage
     import tie_aware as TA
 
     for b in range(B):
@@ -109,8 +114,6 @@ def test_superglue_vs_oracle_fullsize(dev, B, M, N, precision):
         r0 = TA.check_matches(p["matches0"][b].cpu(), ref["matches0"][b], ref["log_assignment"][b], 0.2, eps)
         r1 = TA.check_matches(p["matches1"][b].cpu(), ref["matches1"][b], ref["log_assignment"][b].t(), 0.2, eps)
         print(f"[{precision}] pair {b}: matches0 {r0['differing']}/{r0['compared']} differ, matches1 {r1['differing']}/{r1['compared']} differ (near-ties, eps {eps:.1e})")
-    same = p["matches0"].cpu() == ref["matches0"]
-    torch.testing.assert_close(p["matching_scores0"].cpu()[same], ref["matching_scores0"][same], rtol=0, atol=2e-4)
     # oracle-independent: mutual consistency (superglue.py:288-298)
     m0, m1 = p["matches0"], p["matches1"]
     idx = torch.arange(M, device=dev)[None].expand(B, -1)

@@ -1,4 +1,4 @@
-"""The tie-aware comparison (tests/tie_aware.py) has teeth: it accepts near-tie differences of the oracle's own
+"""The tie-aware comparison (oracle/tie_aware.py) has teeth: it accepts near-tie differences of the oracle's own
 decisions and nothing else.  CPU only: the "other implementation" is the oracle with its floats perturbed."""
 import pytest
 import torch
