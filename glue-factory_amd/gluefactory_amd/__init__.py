@@ -6,6 +6,7 @@ Module paths usable as `model.extractor.name` / `model.matcher.name` in a glue-f
     gluefactory_amd.superpoint        MagicLeap-layout SuperPoint   (gluefactory_nonfree/superpoint.py)
     gluefactory_amd.superpoint_open   open SuperPoint               (models/extractors/superpoint_open.py)
     gluefactory_amd.lightglue         LightGlue matcher             (models/matchers/lightglue.py)
+    gluefactory_amd.lightglue_pretrained  the same behind the `lightglue` package's conf (models/matchers/lightglue_pretrained.py)
     gluefactory_amd.superglue         SuperGlue matcher             (gluefactory_nonfree/superglue.py)
     gluefactory_amd.gluestick         GlueStick point+line matcher  (models/matchers/gluestick.py)
     gluefactory_amd.wireframe         points + segments -> wireframe (models/lines/wireframe.py)

@@ -206,15 +206,25 @@ class NativeModel(BaseModel):
         loaded, unexpected = self._ingest(own)
         if strict:
             unexpected_keys.extend(prefix + k for k in unexpected)
-            missing = sorted(had - set(loaded)) if had else ([] if loaded else ["*"])
-            missing_keys.extend(prefix + k for k in missing)
+            missing_keys.extend(prefix + k for k in self._missing_after(had, loaded))
+
+    def _missing_after(self, had, loaded):
+        """Keys still absent after a load: against the set the model NEEDS where the subclass states it (`_required_keys`), so a first,
+        partial load reports what is missing; otherwise against what it held before."""
+        need = self._required_keys()
+        if need is not None:
+            return sorted(set(need) - set(self.weights.state_dict()))
+        return sorted(had - set(loaded)) if had else ([] if loaded else ["*"])
+
+    def _required_keys(self):
+        return None
 
     def load_state_dict(self, state_dict, strict=False, **kw):
         had = set(self.weights.state_dict())
         loaded, unexpected = self._ingest(state_dict)
         if not loaded:
             raise RuntimeError("state_dict holds none of the tensors this model needs")
-        missing = sorted(had - set(loaded))
+        missing = self._missing_after(had, loaded)
         if strict and (missing or unexpected):
             raise RuntimeError(f"load_state_dict(strict=True): missing {missing}, unexpected {unexpected}")
         from torch.nn.modules.module import _IncompatibleKeys
@@ -224,8 +234,16 @@ class NativeModel(BaseModel):
     def state_dict(self, *a, **kw):
         return self.weights.state_dict(*a, **kw)
 
+    def _has_weights(self):
+        return len(self.weights._modules) + len(self.weights._buffers) > 0
+
     def is_initialized(self):
-        return bool(self.are_weights_initialized) and len(self.weights._modules) + len(self.weights._buffers) > 0
+        return bool(self.are_weights_initialized) and self._has_weights()
+
+    def set_initialized(self, to=True):
+        # a composite's load_state_dict(strict=False) marks every child afterwards (base_model.py:132-136), also one that received no
+        # tensors (an extractor-only checkpoint): such a child stays uninitialized instead of uploading an empty weight set later
+        self.are_weights_initialized = bool(to) and self._has_weights()
 
     def _rename_keys(self, sd):
         return sd
@@ -250,7 +268,7 @@ class NativeModel(BaseModel):
             self._engine.set_precision(self.conf.get("precision", "f16x3"))
             self._uploaded_version = -1
         if self._uploaded_version != self._weights_version:
-            if not self.are_weights_initialized:
+            if not self.is_initialized():
                 raise RuntimeError(f"{type(self).__name__}: weights are not loaded (pass conf.weights=<path> or call load_state_dict)")
             self._engine.set_weights(self.which, self.weights.state_dict(), self._variant_or_layers())
             self._uploaded_version = self._weights_version

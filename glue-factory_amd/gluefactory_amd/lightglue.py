@@ -57,6 +57,15 @@ class LightGlue(NativeModel):
     def _variant_or_layers(self):
         return int(self.conf.n_layers)
 
+    def _required_keys(self):
+        """state_dict keys of lightglue.py:340-357 that the plain forward reads (the `token_confidence.{i}` heads only with adaptive depth)."""
+        keys = ["posenc.Wr.weight"]
+        for i in range(int(self.conf.n_layers)):
+            for blk, lins in (("self_attn", ("Wqkv", "out_proj")), ("cross_attn", ("to_qk", "to_v", "to_out"))):
+                keys += [f"transformers.{i}.{blk}.{n}.{p}" for n in lins + ("ffn.0", "ffn.1", "ffn.3") for p in ("weight", "bias")]
+            keys += [f"log_assignment.{i}.{n}.{p}" for n in ("matchability", "final_proj") for p in ("weight", "bias")]
+        return keys
+
     def _forward(self, data):
         k0, k1 = data["keypoints0"], data["keypoints1"]
         size0 = size1 = None

@@ -55,6 +55,11 @@ class SuperPoint(NativeModel):
     def _wants(self, key):
         return key.split(".")[0] in self._prefixes
 
+    def _required_keys(self):
+        if self.variant == _native.MG_SP_MAGICLEAP:  # superpoint.py:179-196
+            return [f"{n}.{p}" for n in self._prefixes for p in ("weight", "bias")]
+        return None
+
     def _variant_or_layers(self):
         return self.variant
 

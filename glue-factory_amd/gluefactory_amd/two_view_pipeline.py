@@ -17,6 +17,8 @@ _ALIASES = {
     "gluefactory.models.extractors.superpoint_open": "gluefactory_amd.superpoint_open",
     "matchers.lightglue": "gluefactory_amd.lightglue",
     "gluefactory.models.matchers.lightglue": "gluefactory_amd.lightglue",
+    "matchers.lightglue_pretrained": "gluefactory_amd.lightglue_pretrained",  # configs/eval/superpoint+lightglue-official.yaml:9
+    "gluefactory.models.matchers.lightglue_pretrained": "gluefactory_amd.lightglue_pretrained",
     "gluefactory_nonfree.superglue": "gluefactory_amd.superglue",
     "matchers.nearest_neighbor_matcher": "gluefactory_amd.nearest_neighbor_matcher",
     "matchers.gluestick": "gluefactory_amd.gluestick",

@@ -99,25 +99,22 @@ def test_export_key_filter_and_errors(tmp_path):
         pass
 
 
-def test_cache_loader_reads_back_what_the_reference_reads(golden, tmp_path):
-    """Batched export -> gluefactory_amd.cache_loader == what the reference's own CacheLoader returned for the same file
+def test_read_back_equals_what_the_reference_loader_reads(golden, tmp_path):
+    """Batched export -> gluefactory_amd.export.read_predictions == what the reference's own CacheLoader returned for the same file
     (recorded by oracle/tools/make_goldens.py after checking that it reads the reference's and the batched export identically)."""
-    from gluefactory_amd.cache_loader import CacheLoader
-    from gluefactory_amd.export import export_predictions
+    from gluefactory_amd.export import export_predictions, read_predictions
 
     g = golden("export_h5")
     pairs = export_fixture()
     for half in (False, True):
         path = tmp_path / f"pred{int(half)}.h5"
         export_predictions(_batched_loader(pairs, 3), _model, path, as_half=half, h5=_H5)
-        cl = CacheLoader({"path": str(path), "collate": False}, h5=_H5)
         for name, _, s0, s1 in pairs:
-            got = cl({"name": [name], "view0": {"scales": s0[None]}, "view1": {"scales": s1[None]}})
+            got = read_predictions(path, [name], {"view0": {"scales": s0[None]}, "view1": {"scales": s1[None]}}, h5=_H5)[0]
             want = {k.split("|", 2)[2]: g[k] for k in g.keys() if k.startswith(f"cache{int(half)}|{name}|")}
             assert sorted(got) == sorted(want) and len(want) == 10
             for k in want:
                 assert got[k].dtype == want[k].dtype and torch.equal(got[k], want[k]), (half, name, k)
-    # collated batches of equal-sized items
-    cl = CacheLoader({"path": str(path), "data_keys": ["matching_scores0"], "collate": True}, h5=_H5)
-    out = cl({"name": [pairs[0][0], pairs[3][0]], "view0": {"scales": torch.ones(2, 2)}, "view1": {"scales": torch.ones(2, 2)}})
-    assert out["matching_scores0"].shape[0] == 2
+    # a key subset of several pairs, coordinates left in original-image pixels
+    out = read_predictions(path, [pairs[0][0], pairs[3][0]], keys=["matching_scores0", "keypoints0"], h5=_H5)
+    assert len(out) == 2 and sorted(out[0]) == ["keypoints0", "matching_scores0"]

@@ -1,5 +1,5 @@
 """SURVEY 8f rank 2 on real GPU output: a batched SuperPoint + LightGlue result goes through the batched exporter
-(gluefactory_amd.export, the reference's h5 layout), is read back by the cache loader (gluefactory_amd.cache_loader, checked on
+(gluefactory_amd.export, the reference's h5 layout), is read back by its inverse (gluefactory_amd.export.read_predictions, checked on
 the CPU against what the reference's own CacheLoader reads), and the cached features drive the pipeline's `cache` path
 (two_view_pipeline.py:62-70).  h5py is not installed in this image: the h5 calls go to an in-memory stand-in."""
 import os
@@ -20,8 +20,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_export_read_back_and_cached_features(tmp_path):
-    from gluefactory_amd.cache_loader import CacheLoader
-    from gluefactory_amd.export import export_predictions
+    from gluefactory_amd.export import export_predictions, read_predictions
     from gluefactory_amd.two_view_pipeline import TwoViewPipeline
 
     dev = torch.device("cuda:0")
@@ -47,9 +46,8 @@ def test_export_read_back_and_cached_features(tmp_path):
     assert sorted(_H5.files[str(path)]) == sorted(names)
     direct = {k: v.cpu() for k, v in pipe({k: ({kk: vv.to(dev) for kk, vv in v.items()} if isinstance(v, dict) else v) for k, v in batch.items()}).items()}
 
-    cl = CacheLoader({"path": str(path), "collate": False}, h5=_H5)
     for b, name in enumerate(names):
-        got = cl({"name": [name], "view0": {"scales": scales0[b:b + 1]}, "view1": {"scales": scales1[b:b + 1]}})
+        got = read_predictions(path, [name], {"view0": {"scales": scales0[b:b + 1]}, "view1": {"scales": scales1[b:b + 1]}}, h5=_H5)[0]
         assert sorted(got) == sorted(keys)
         for k in keys:
             want = direct[k][b]
@@ -61,7 +59,7 @@ def test_export_read_back_and_cached_features(tmp_path):
     cached.extractor.load_state_dict(O.make_sp_weights(0))
     cached.matcher.load_state_dict(O.make_lg_weights(7, structured=True, final_gain=3.0, match_bias=2.0))
     b = 2
-    feats = cl({"name": [names[b]], "view0": {"scales": scales0[b:b + 1]}, "view1": {"scales": scales1[b:b + 1]}})
+    feats = read_predictions(path, [names[b]], {"view0": {"scales": scales0[b:b + 1]}, "view1": {"scales": scales1[b:b + 1]}}, h5=_H5)[0]
     view = lambda i: {"image_size": size[b:b + 1].to(dev),
                       "cache": {k: feats[k + str(i)][None].to(dev) for k in ("keypoints", "keypoint_scores", "descriptors")}}
     p = cached({"view0": view(0), "view1": view(1)})

@@ -204,3 +204,85 @@ def test_composite_state_dict_round_trip():
     v0 = p.matcher._weights_version
     p.load_state_dict(ckpt)
     assert p.matcher._weights_version == v0 + 1
+
+
+def test_lightglue_pretrained_resolves_for_the_official_config():
+    """configs/eval/superpoint+lightglue-official.yaml names `matchers.lightglue_pretrained` with `features: superpoint` and the adaptive
+    switches at -1: the name resolves through this package's aliases, the conf keys are accepted, other feature types are rejected."""
+    from gluefactory_amd import get_model
+    from gluefactory_amd.two_view_pipeline import TwoViewPipeline
+
+    official = {"extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": 2048, "detection_threshold": 0.0, "nms_radius": 3},
+                "matcher": {"name": "matchers.lightglue_pretrained", "features": "superpoint", "depth_confidence": -1, "width_confidence": -1,
+                            "filter_threshold": 0.1}}
+    p = TwoViewPipeline(official)
+    assert type(p.matcher).__module__ == "gluefactory_amd.lightglue_pretrained"
+    assert p.matcher.conf.features == "superpoint" and p.matcher.conf.filter_threshold == 0.1 and p.matcher.conf.depth_confidence == -1
+    assert p.matcher.required_data_keys == ["view0", "keypoints0", "descriptors0", "view1", "keypoints1", "descriptors1"]  # lightglue_pretrained.py:9-16
+    assert not p.is_initialized()
+    p.extractor.load_state_dict(O.make_sp_weights(0))
+    p.matcher.load_state_dict(O.make_lg_weights(0))  # the released checkpoint uses these key names (lightglue.py:369-385)
+    assert p.is_initialized()
+    M = get_model("matchers.lightglue_pretrained")  # the reference's short name, as gluefactory.models.get_model tries it
+    assert M is type(p.matcher)
+    assert M({}).conf.depth_confidence == 0.95 and M({}).conf.width_confidence == 0.99  # the package's own defaults
+    with pytest.raises(NotImplementedError):
+        M({"features": "disk"})
+    with pytest.raises(ValueError):
+        M({"features": "orb"})
+    with pytest.raises(AssertionError, match="Missing key view0"):
+        m = M({})
+        m.load_state_dict(O.make_lg_weights(0))
+        m({"keypoints0": 0, "keypoints1": 0, "descriptors0": 0, "descriptors1": 0})
+
+
+def test_lightglue_pretrained_resolves_through_the_reference_registry():
+    """The reference's own registry (gluefactory/models/__init__.py:7-30) and TwoViewPipeline around this package's module path.  Runs only
+    where the reference tree is present (the build container); the GPU box has no /root/reference."""
+    import sys
+
+    ref = "/root/reference"
+    shim = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "tools", "_shim")
+    if not os.path.isdir(ref):
+        pytest.skip("reference tree not present")
+    added = [p for p in (ref, shim) if p not in sys.path]
+    sys.path[:0] = added
+    try:
+        from gluefactory.models import get_model as ref_get_model
+
+        cls = ref_get_model("gluefactory_amd.lightglue_pretrained")
+        assert cls.__module__ == "gluefactory_amd.lightglue_pretrained"
+        pipe = ref_get_model("two_view_pipeline")({
+            "extractor": {"name": "gluefactory_amd.superpoint", "max_num_keypoints": 1024, "detection_threshold": 0.0, "nms_radius": 3},
+            "matcher": {"name": "gluefactory_amd.lightglue_pretrained", "features": "superpoint", "depth_confidence": -1, "width_confidence": -1,
+                        "filter_threshold": 0.1}})
+        assert not pipe.is_initialized()
+        sd = {**{"extractor." + k: v for k, v in O.make_sp_weights(0).items()}, **{"matcher." + k: v for k, v in O.make_lg_weights(0).items()}}
+        res = pipe.load_state_dict(sd, strict=False)
+        assert not res.missing_keys and not res.unexpected_keys and pipe.is_initialized()
+    finally:
+        for p in added:
+            sys.path.remove(p)
+        for name in [n for n in sys.modules if n == "gluefactory" or n.startswith("gluefactory.") or n == "omegaconf" or n.startswith("omegaconf.")]:
+            del sys.modules[name]
+
+
+def test_partial_checkpoints_leave_children_uninitialized():
+    """An extractor-only checkpoint loaded into the composite must not mark the matcher ready (it would upload an empty weight set)."""
+    from gluefactory_amd import get_model
+    from gluefactory_amd.two_view_pipeline import TwoViewPipeline
+
+    p = TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint"}, "matcher": {"name": "matchers.lightglue"}})
+    p.load_state_dict({"extractor." + k: v for k, v in O.make_sp_weights(0).items()}, strict=False)
+    assert p.extractor.is_initialized() and not p.matcher.is_initialized() and not p.is_initialized()
+    with pytest.raises(RuntimeError, match="weights are not loaded|no CPU fallback"):
+        p.matcher.engine("cuda:0" if torch.cuda.is_available() else "cpu")
+    # strict loading reports what a first, partial load still lacks
+    lg = get_model("lightglue")({})
+    W = O.make_lg_weights(0)
+    part = {k: v for k, v in W.items() if not k.startswith("transformers.8.")}
+    with pytest.raises(RuntimeError, match="transformers.8.self_attn.Wqkv.weight"):
+        lg.load_state_dict(part, strict=True)
+    sp = get_model("superpoint")({})
+    res = sp.load_state_dict({k: v for k, v in O.make_sp_weights(0).items() if not k.startswith("convDb")})
+    assert res.missing_keys == ["convDb.bias", "convDb.weight"]
