@@ -1001,7 +1001,7 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
 // ------------------------------------------------------------------------------------------------
 // The LightGlue forward; `ad` != nullptr selects the adaptive depth / width variant (batch 1).
 struct LgAdaptive {
-    float depth = -1.f, width = -1.f;
+    double depth = -1.0, width = -1.0;  // Python floats in the reference: kept unrounded up to the point of comparison
     int32_t* prune0 = nullptr;  // (M) / (N) int32, device
     int32_t* prune1 = nullptr;
     int32_t* out_dims = nullptr;  // host: M', N', layers run
@@ -1014,7 +1014,7 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
     if (B < 1 || M < 1 || N < 1) return fail(MG_ERR_ARG, "empty input");
     if (conf->num_heads != 4) return fail(MG_ERR_ARG, "num_heads must be 4 (descriptor_dim 256, head_dim 64)");
     if (conf->n_layers < 1) return fail(MG_ERR_ARG, "n_layers must be >= 1");
-    const bool do_stop = ad && ad->depth > 0.f, do_prune = ad && ad->width > 0.f;
+    const bool do_stop = ad && ad->depth > 0.0, do_prune = ad && ad->width > 0.0;
     if (ad && B != 1) return fail(MG_ERR_ARG, "adaptive depth / width needs batch 1 (lightglue.py:476,:481 assert it)");
     HIPCHK(hipSetDevice(h->device));
     if (ad) {
@@ -1182,12 +1182,12 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
             HIPCHK(hipMemcpyAsync(&below, CNT + 2, sizeof(int32_t), hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
             const float ratio = 1.0f - (float)below / (float)(M + N);
-            if (ratio > ad->depth) { last = i; break; }
+            if (ratio > (float)ad->depth) { last = i; break; }  // an fp32 tensor compared with the Python scalar: in fp32 (:559)
         }
         if (do_prune) {  // :480-497 with get_pruning_mask :541-549
             launch_matchability(X, (long long)T, h->lg_match_w[i], h->lg_match_b[i], Z, s);
             LgPruneArgs pa;
-            pa.z = Z; pa.zt = do_stop ? ZT : nullptr; pa.thr_tok = thr; pa.thr_keep = (float)(1.0 - (double)ad->width);
+            pa.z = Z; pa.zt = do_stop ? ZT : nullptr; pa.thr_tok = thr; pa.thr_keep = (float)(1.0 - ad->width);  // fp32(1 - width_confidence) from the double, lightglue.py:545
             pa.M = Mc; pa.N = Nc; pa.ind = IND; pa.ind_out = IND2; pa.prune0 = ad->prune0; pa.prune1 = ad->prune1; pa.src = reinterpret_cast<int32_t*>(ST);
             pa.counts = CNT;
             pa.x = X; pa.xs = f16 ? XS : nullptr; pa.enc = ENC; pa.x_out = X2; pa.xs_out = f16 ? XS2 : nullptr; pa.enc_out = ENC2;  // no SH8 copy in f32 mode
@@ -1287,7 +1287,7 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
                   ref_desc1, stream, nullptr);
 }
 
-int mg_lg_forward_adaptive(mg_handle h, const mg_lg_conf* conf, float depth_confidence, float width_confidence, const float* kpts0,
+int mg_lg_forward_adaptive(mg_handle h, const mg_lg_conf* conf, double depth_confidence, double width_confidence, const float* kpts0,
                            const float* kpts1, const float* desc0, const float* desc1, const float* size0, const float* size1, int M, int N,
                            int64_t* matches0, int64_t* matches1, float* mscores0, float* mscores1, float* log_assignment, float* ref_desc0,
                            float* ref_desc1, int32_t* prune0, int32_t* prune1, int32_t* out_dims, void* stream) {

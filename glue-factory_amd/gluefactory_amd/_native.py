@@ -6,7 +6,7 @@ through PyTorch ops or the CPU oracle.
 """
 import ctypes
 import os
-from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
+from ctypes import POINTER, Structure, c_char_p, c_double, c_float, c_int, c_int32, c_int64, c_size_t, c_void_p
 
 import torch
 
@@ -78,7 +78,7 @@ def lib():
                                c_void_p, c_void_p]
     L.mg_sp_sample.argtypes = [c_void_p, POINTER(SpConf), c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p]
     L.mg_lg_forward.argtypes = [c_void_p, POINTER(LgConf)] + [c_void_p] * 6 + [c_int] * 3 + [c_void_p] * 8
-    L.mg_lg_forward_adaptive.argtypes = [c_void_p, POINTER(LgConf), c_float, c_float] + [c_void_p] * 6 + [c_int] * 2 + [c_void_p] * 9 + [POINTER(c_int32), c_void_p]
+    L.mg_lg_forward_adaptive.argtypes = [c_void_p, POINTER(LgConf), c_double, c_double] + [c_void_p] * 6 + [c_int] * 2 + [c_void_p] * 9 + [POINTER(c_int32), c_void_p]
     L.mg_sg_forward.argtypes = [c_void_p, POINTER(SgConf)] + [c_void_p] * 8 + [c_int] * 3 + [c_void_p] * 7
     L.mg_gs_forward.argtypes = [c_void_p, POINTER(GsConf)] + [c_void_p] * 14 + [c_int] * 5 + [c_void_p] * 12
     L.mg_wf_filter.argtypes = [c_void_p] + [c_void_p] * 5 + [c_int] * 3 + [c_float] + [c_void_p] * 5

@@ -65,7 +65,7 @@ int mg_create(int device, mg_handle* out);
 int mg_destroy(mg_handle h);
 const char* mg_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
-#define MG_ABI_VERSION 9 /* bumped whenever an entry point or a conf struct changes */
+#define MG_ABI_VERSION 10 /* bumped whenever an entry point or a conf struct changes */
 int mg_abi_version(void);   /* == MG_ABI_VERSION of the header the library was built from */
 
 /* -- arithmetic ------------------------------------------------------------------------------
@@ -134,8 +134,11 @@ int mg_lg_forward(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
  * points: -1 / 0, :500-508); prune0/1 (M)/(N) int32 = 1 + pruning rounds survived (:463-466,:487,:495).
  * log_assignment (optional, room for (M+1)(N+1) floats) is (M'+1, N'+1) and ref_desc0/1 (optional, (M,256)/(N,256)) hold M' / N'
  * rows for the surviving points; out_dims (HOST, 3 ints) receives M', N' and the number of layers run.  Synchronises the stream
- * once per layer (the decisions are made on the host, as `if self.check_if_stop(...)` / `torch.where` do in the reference). */
-int mg_lg_forward_adaptive(mg_handle h, const mg_lg_conf* conf, float depth_confidence, float width_confidence,
+ * once per layer (the decisions are made on the host, as `if self.check_if_stop(...)` / `torch.where` do in the reference).
+ * The two confidences are DOUBLES, as the reference holds them (Python floats): it compares fp32 tensors with the Python scalars
+ * `1 - width_confidence` / `depth_confidence`, i.e. with fp32(1.0 - width) formed from the unrounded double -- rounding width to
+ * fp32 first moves that threshold by ~1e-8 (ten fp32 ulps at 0.01). */
+int mg_lg_forward_adaptive(mg_handle h, const mg_lg_conf* conf, double depth_confidence, double width_confidence,
                            const float* kpts0, const float* kpts1, const float* desc0, const float* desc1,
                            const float* size0, const float* size1, int M, int N, int64_t* matches0, int64_t* matches1,
                            float* mscores0, float* mscores1, float* log_assignment, float* ref_desc0, float* ref_desc1,
