@@ -44,8 +44,9 @@ def all_gather_matches(pred, group=None, with_keypoints=False, force=False, num_
     One packed buffer per rank -> a single `all_gather_into_tensor` call.  Shards may differ in size
     (`shard_range` hands out blocks that differ by one pair when B % world != 0): every rank pads its buffer to the
     largest shard and the padding rows are dropped on return.  The shard sizes come from `num_pairs` (the global
-    batch, split by `shard_range`) when given -- no extra traffic -- and from one tiny all-gather of the local row
-    counts otherwise.  `force` runs the collective even in a one-rank group (the single-GPU test of the RCCL path).
+    batch, split by `shard_range`) when given -- no extra traffic, no host synchronisation: what bench.py and any caller that
+    knows its global batch uses -- and from one tiny all-gather of the local row counts otherwise (that branch reads the counts
+    back to the host, one D2H sync per call: the output's row count has to be known to allocate it).  `force` runs the collective even in a one-rank group (the single-GPU test of the RCCL path).
     `stats`, if a dict, receives `bytes_sent` / `bytes_received` of this call.
     """
     keys = [k for k in GATHER_KEYS + (OPTIONAL_KEYS if with_keypoints else ()) if k in pred]
