@@ -158,8 +158,15 @@ def test_shard_forward_gather_step(world, n_pairs):
     """configs[2]: 256 pairs over 8 ranks (32 each); 250 over 8 (shards of 32 and 31) and 30 over 4 (8, 8, 7, 7) exercise the padding.
     shard_batch -> per-rank forward -> one packed all-gather reproduces the single-process result on every rank."""
     os.environ["PYTHONPATH"] = os.pathsep.join([ROOT, os.path.join(ROOT, "glue-factory_amd"), os.path.join(ROOT, "tests"), os.environ.get("PYTHONPATH", "")])
-    torch.set_num_threads(1)
-    mgr = mp.Manager()
-    out = mgr.dict()
-    mp.spawn(_step_worker, args=(world, _free_port(), n_pairs, out), nprocs=world, join=True)
+    old = os.environ.get("OMP_NUM_THREADS")
+    os.environ["OMP_NUM_THREADS"] = "1"  # eight ranks on eight cores; set for the children only (this process keeps its thread count:
+    try:                                   # the oracle-vs-golden tests compare fp32 sums whose order depends on it)
+        mgr = mp.Manager()
+        out = mgr.dict()
+        mp.spawn(_step_worker, args=(world, _free_port(), n_pairs, out), nprocs=world, join=True)
+    finally:
+        if old is None:
+            os.environ.pop("OMP_NUM_THREADS", None)
+        else:
+            os.environ["OMP_NUM_THREADS"] = old
     assert all(out[r] for r in range(world)) and len(out) == world
