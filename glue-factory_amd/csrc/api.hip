@@ -923,12 +923,14 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
             ConvF16Args a;
             a.Wt = L.Wh; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
             a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = 1; a.relu = 1;
+            a.staged = (h->taps.count("sp.conv_staged") || h->taps.count("sp.conv1ab_staged")) ? 1 : h->taps.count("sp.conv1ab_valu") ? 2 : 0;
             launch_conv1ab_f16x3(a, c1, s);
         } else if (f16) {
             ConvF16Args a;
             a.in = st.in; a.Wt = L.Wh; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
             a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = st.pool; a.relu = 1;
             a.out_f32 = 0;
+            a.staged = h->taps.count("sp.conv_staged") ? 1 : 0;
             launch_conv3x3_f16x3(a, s);
         } else {
             ConvArgs a;
@@ -942,8 +944,7 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
         }
         continue;
     }
-    static const bool unfused_heads = getenv("MG_HEADS_UNFUSED") != nullptr;  // A/B timing of the three-launch form only
-    if (f16 && !unfused_heads && !h->taps.count("sp.logits")) {
+    if (f16 && !h->taps.count("sp.logits")) {  // (a request for the logits tap selects the three-launch form)
         ProfScope ps(h, s, "sp.heads");  // convPb + soft-max + depth-to-space (heads_f16.hip)
         HeadsF16Args a;
         a.in = cP; a.W = h->convPb.Wh; a.Npad = h->convPb.Npad; a.bias = h->convPb.bias; a.post_scale = h->convPb.ps; a.post_shift = h->convPb.pt;
@@ -1056,8 +1057,7 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
     size_t T0 = T0_in, T = Tin;
 
     // the three-launch form stays reachable for A/B timing (environment) and for the equivalence test (debug tap request)
-    static const bool unfused_env = getenv("MG_FFN_UNFUSED") != nullptr;
-    const bool unfused_ffn = unfused_env || h->taps.count("lg.unfused_ffn");
+    const bool unfused_ffn = h->taps.count("lg.unfused_ffn") != 0;
     auto ffn = [&](const LgBlock& blk) {
         if (f16 && !unfused_ffn) {
             ProfScope ps(h, s, "lg.ffn");
@@ -1212,36 +1212,23 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
     float* MD = QKV;  // reuse: (T,256) projected descriptors
     {
         ProfScope ps(h, s, "lg.gemm.final_proj");
-        if (f16) {
-            GemmF16Args g = lin_args_f16(fproj, XS, 256, (int)T);
-            g.Cs = MD; g.ldcs = 256;
-            g.scale = 0.25f; g.scale_cols = 256;
-            launch_gemm_f16x3(g, s);
-        } else {
-            GemmArgs g = lin_args(fproj, X, 256, (int)T, MD, 256);
-            g.scale = 0.25f;  // / 256^(1/4)
-            g.scale_cols = 256;
-            launch_gemm(g, s);
-        }
+        // both arithmetic modes: the projection and the similarity below run on the fp32 MFMA with float64 stage sums (gemm.hip PRECISE):
+        // log_assignment = 2 sim - lse_row - lse_col needs sim to a fraction of an fp32 ulp to stay within 1e-4 of the exact value
+        GemmArgs g = lin_args(fproj, X, 256, (int)T, MD, 256);
+        g.scale = 0.25f;  // / 256^(1/4), exact
+        g.scale_cols = 256;
+        g.precise = 1;
+        launch_gemm(g, s);
     }
     {
         ProfScope ps(h, s, "lg.gemm.sim");
-        if (f16) {
-            // sim[b] (M x N): lanes = image-0 tokens ("A" rows of the launcher), MFMA rows = image-1 tokens
-            GemmF16Args g;
-            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
-            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = SIM; g.ldc = Nc; g.M = Mc; g.N = Nc; g.K = 256;
-            g.batch = B; g.strideA = (long long)Mc * 256; g.strideW = (long long)Nc * 256; g.strideC = (long long)Mc * Nc;
-            launch_gemm_f16x3(g, s);
-        } else {
-            GemmArgs g;
-            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
-            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = SIM; g.ldc = Nc; g.M = Mc; g.N = Nc; g.K = 256;
-            g.batch = B; g.strideA = (long long)Mc * 256; g.strideW = (long long)Nc * 256; g.strideC = (long long)Mc * Nc;
-            launch_gemm(g, s);
-        }
+        GemmArgs g;  // sim[b] (M x N) = mdesc0[b] mdesc1[b]^T
+        g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+        g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+        g.C = SIM; g.ldc = Nc; g.M = Mc; g.N = Nc; g.K = 256;
+        g.batch = B; g.strideA = (long long)Mc * 256; g.strideW = (long long)Nc * 256; g.strideC = (long long)Mc * Nc;
+        g.precise = 1;
+        launch_gemm(g, s);
     }
     // the adaptive variant assigns in the surviving points' index space and scatters back to the original one afterwards
     long long* am0 = reinterpret_cast<long long*>(matches0);
@@ -1370,8 +1357,7 @@ struct GnnRun {
                 launch_attention(a, s);
             }
         }
-        static const bool unfused_env = getenv("MG_FFN_UNFUSED") != nullptr;
-        const bool unfused_ffn = unfused_env || h->taps.count("lg.unfused_ffn");
+        const bool unfused_ffn = h->taps.count("lg.unfused_ffn") != 0;
         if (f16 && !unfused_ffn) {
             ProfScope ps(h, s, t + ".ffn");
             FfnF16Args a;

@@ -1270,6 +1270,372 @@ __global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p
 #endif
 }
 
+// conv1a + conv1b + pool on the stage machinery of conv3x3_dma_kernel.  Differences to the register-staged kernel above:
+//   * the weight rows of conv1b go through the same four-slot LDS-DMA ring, one barrier per filter row -- the two barriers
+//     and the register -> LDS weight copy per chunk are gone; all eight waves multiply all the time;
+//   * round 3: conv1a itself runs on the matrix pipe.  It is a K = 9 contraction (superpoint.py:209): with the split operands
+//     the three products hi.hi + hi.lo + lo.hi of all nine taps are 27 of the 32 k-slots of ONE v_mfma_f32_16x16x32_f16 --
+//     A = the chunk's 16 channels ([W_hi taps 0-7 | W_hi taps 0-7 | W_lo taps 0-7 | W_hi8, W_hi8, W_lo8, 0...]), B = 16 halo
+//     pixels ([g_hi | g_lo | g_hi | g_hi8, g_lo8, g_hi8, 0...]), C = the bias.  The B fragment of a pixel group (its 3x3 gray
+//     window as fp16 halves) does not depend on the chunk: a wave builds the fragments of its five pixel groups ONCE per image
+//     tile from the packed (hi | lo << 16) gray tile and keeps them in 20 registers; per chunk it issues five 16-cycle MFMAs and
+//     five finishes (ReLU / zero outside the image as one v_med3, split, two 8-byte LDS writes: a lane owns 4 channels of one
+//     pixel).  Round 2 computed the taps with packed fp32 FMAs between the MFMAs: 6.3 VALU instructions per MFMA, 17 % LDS bank
+//     conflicts from the tap-table and gray-pair reads, 55 % MFMA-busy (profiles/r02_z_f16x3_sq_counters.json);
+//   * the gray tile of the next image tile is fetched during chunk 0 (six unconditional buffer loads per thread: a
+//     one-channel image is read three times so that the VMEM count does not depend on C), converted, split and stored into
+//     the second gray buffer during chunk 1; the next tile's fragments are built in the third stage of chunk 2 (the last
+//     produce step of this tile is over by then) and used by the produce steps of chunk 3.
+// conv1b's accumulation order is that of conv1ab_f16x3_kernel; conv1a differs from it by the arithmetic (split-fp16 products on
+// the matrix pipe instead of fp32 FMAs): same error class as every other layer of this mode (tests/test_gpu_conv_dma.py).
+__device__ __forceinline__ f32x4 mfma16x16(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+__global__ __launch_bounds__(512, 2) void conv1ab_mfma_kernel(const ConvF16Args p, const Conv1aArgs c1) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    constexpr int WX = 2, TH = 16, TW = 32;
+    constexpr int PW = ((TW + 2 + 7) / 16) * 16 + 8;
+    constexpr int NPIX = (TH + 2) * (TW + 2);
+    constexpr int IN_SZ = (TH + 2) * PW * 4;
+    constexpr int WS = 3 * 64 * 4, WR = 4, NWA = 2, WLP = WS / (8 * NWA);  // two 48-lane weight pieces per wave and stage
+    constexpr int E = 4;                              // pooled output: four stores per wave and tile
+    constexpr int NGL = 6;                            // gray-tile loads per thread and tile (2 pixels x 3 channels)
+    constexpr int GH = TH + 4, GW = TW + 4, GP = GW + 1, GSZ = ((GH * GP + 3) / 4) * 4;
+    static_assert(GH * GW <= 512 + 256, "second gray pixel only on threads 0..255");
+    constexpr int NG = (NPIX + 15) / 16, NF = (NG + 7) / 8;  // 39 groups of 16 halo pixels, five per wave
+    constexpr int RAW = 3 * 512 + 3 * 256 + 64;       // raw image values: first pixel of every thread, second pixel of waves 0-3, a dump slot
+    // ONE LDS array: [2 halo tiles][4 weight stages][2 gray tiles][conv1a A fragments][conv1a bias][conv1b bias][raw image values of the next gray tile]
+    __shared__ u32x4 s_all[2 * IN_SZ + WR * WS + 2 * GSZ / 4 + 4 * 64 + 64 / 4 + 64 / 4 + RAW / 4];
+    static_assert(sizeof(s_all) <= 160 * 1024, "LDS");
+    u32x4* const s_in = s_all;
+    u32x4* const s_w = s_all + 2 * IN_SZ;
+    unsigned* const s_g = reinterpret_cast<unsigned*>(s_all + 2 * IN_SZ + WR * WS);  // packed fp16 halves of the gray value: hi | lo << 16
+    u32x4* const s_a = reinterpret_cast<u32x4*>(s_g + 2 * GSZ);                      // [chunk][lane]: A operand of the conv1a MFMA
+    float* const s_b1 = reinterpret_cast<float*>(s_a + 4 * 64);                      // conv1a bias
+    float* const s_bias = s_b1 + 64;
+    float* const s_raw = s_bias + 64;                 // written by LDS-DMA, read back by the same thread
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int tiles = tiles_x * tiles_y, total = tiles * p.B;
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wt), 0, 0x7fffffff, 0x00020000);
+
+    struct Tile { int b, y0, x0; };
+    auto tile_of = [&](int id) {
+        int logical = id;
+        if ((total & 7) == 0) logical = (id & 7) * (total >> 3) + (id >> 3);
+        const int tl = logical % tiles;
+        return Tile{logical / tiles, (tl / tiles_x) * TH, (tl % tiles_x) * TW};
+    };
+
+    // A operand of the conv1a MFMA, per chunk: lane l = row (channel) l & 15, k-block q = l >> 4 (8 halves):
+    //   q = 0, 1: W_hi of taps 0-7;  q = 2: W_lo of taps 0-7;  q = 3: W_hi8, W_hi8, W_lo8, 0, 0, 0, 0, 0
+    if (t < 4 * 64) {
+        const int ch = (t >> 6) * 16 + (t & 15), q = (t >> 4) & 3;
+        f16x8 a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int tap = q < 3 ? e : 8;
+            const float w = c1.w[ch * 9 + tap];
+            const _Float16 wh = (_Float16)w, wl = (_Float16)(w - (float)wh);
+            a[e] = q < 2 ? wh : q == 2 ? wl : e < 2 ? wh : e == 2 ? wl : (_Float16)0.f;
+        }
+        s_a[t] = __builtin_bit_cast(u32x4, a);
+    }
+    if (t < 64) {
+        s_b1[t] = c1.bias[t];
+        s_bias[t] = t < p.Cout ? p.bias[t] : 0.f;
+    }
+
+    // gray tile (RGB -> gray as superpoint.py:204-206), zero outside the image: thread t owns tile pixels t and t + 512
+    // (the raw values travel global -> LDS by DMA and are converted a chunk later: held in registers across a chunk they were spilled)
+    const int HWb = c1.H * c1.W * 4;
+    auto gray_rsrc = [&](const Tile& tl) {
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c1.image) + (long long)tl.b * c1.C * c1.H * c1.W, 0, c1.C * HWb, 0x00020000);
+    };
+    auto gray_load = [&](const __amdgpu_buffer_rsrc_t& rs, const Tile& tl, int j) {  // load j of NGL: pixel j / 3, channel j % 3
+        const int ch = c1.C == 3 ? j % 3 : 0;
+        const int i = wu * 64 + fresh_lane() + 512 * (j / 3), gy = i / GW, gx = i - gy * GW;  // recomputed per load: nothing kept live
+        const int yy = tl.y0 + gy - 2, xx = tl.x0 + gx - 2;
+        const bool ok = i < GH * GW && (unsigned)yy < (unsigned)c1.H && (unsigned)xx < (unsigned)c1.W;
+        // first pixel: [channel][512 threads]; second pixel (tile pixels 512..719): waves 0-3 only, the others write zeros into a dump slot
+        float* const dst = j < 3 ? s_raw + j * 512 + wu * 64 : wu < 4 ? s_raw + 3 * 512 + (j - 3) * 256 + wu * 64 : s_raw + 3 * 512 + 3 * 256;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, dst, 4, ok ? (yy * c1.W + xx) * 4 : (int)0x80000000, ch * HWb, 0, 0);
+    };
+    auto gray_store = [&](int gb) {
+        const int tt = wu * 64 + fresh_lane();  // addresses recomputed here, not hoisted out of the tile loop (see p_tap)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int i = tt + 512 * k, gy = i / GW, gx = i - gy * GW;
+            if (k == 1 && tt >= 256) break;  // wave-uniform: tile pixels 512.. belong to waves 0-3
+            const float* const src = k == 0 ? s_raw + tt : s_raw + 3 * 512 + tt;
+            const int cs = k == 0 ? 512 : 256;
+            const float r0 = src[0], r1 = src[cs], r2 = src[2 * cs];
+            const float v = c1.C == 3 ? __fadd_rn(__fadd_rn(__fmul_rn(r0, 0.299f), __fmul_rn(r1, 0.587f)), __fmul_rn(r2, 0.114f)) : r0;
+            const _Float16 vh = (_Float16)v, vl = (_Float16)(v - (float)vh);
+            const unsigned pk = (unsigned)__builtin_bit_cast(unsigned short, vh) | ((unsigned)__builtin_bit_cast(unsigned short, vl) << 16);
+            if (i < GH * GW) s_g[gb * GSZ + gy * GP + gx] = pk;
+        }
+    };
+
+    // conv1a on the matrix pipe.  Per image tile and wave: NF = 5 groups of 16 halo pixels (group g = wu + 8 i covers the linear halo
+    // indices 16 g .. 16 g + 15); lane l = pixel l & 15 of the group, k-block q = l >> 4.
+    f16x8 pf[NF];      // B fragments (the pixel's 3x3 gray window as fp16 halves, module header), rebuilt once per tile
+    int wadr[NF];      // byte offset of the lane's 8-byte hi piece inside a halo buffer (its lo piece: ^ 16); a padding slot for pixels past the tile
+    float lim[NF];     // +inf inside the image, 0 outside: relu + zero padding of conv1b's input as one v_med3_f32(x, 0, lim)
+    unsigned gw[9];    // the nine packed gray values of the group under construction (between the two halves of a build step)
+    const int q4 = lane >> 4;
+    auto build_a = [&](int i, int gb, const Tile& tl) {  // first half: request the window, derive the write address and the inside flag
+        const int hp = 16 * (wu + 8 * i) + (fresh_lane() & 15);
+        const int hc = min(hp, NPIX - 1), py = hc / (TW + 2), px = hc - py * (TW + 2);
+        const unsigned* g = s_g + gb * GSZ + py * GP + px;
+#pragma unroll
+        for (int e = 0; e < 9; ++e) gw[e] = g[(e / 3) * GP + (e % 3)];
+        const int yy = tl.y0 + py - 1, xx = tl.x0 + px - 1;
+        lim[i] = (unsigned)yy < (unsigned)c1.H && (unsigned)xx < (unsigned)c1.W ? __builtin_inff() : 0.f;
+        // pixels past the tile (last group only) are parked in the pitch padding of halo row 0 (columns TW + 2 .. PW - 1 are never read)
+        const int P = hp < NPIX ? py * PW + px : TW + 2 + (hp & 3);
+        wadr[i] = (P * 4 + ((q4 & 2) ^ ((P >> 2) & 3))) * 16 + (q4 & 1) * 8;
+    };
+    auto build_b = [&](int i) {  // second half: pack the halves.  q = 0, 2: hi halves of taps 0-7; q = 1: lo halves; q = 3: hi8, lo8, hi8, 0...
+        const unsigned sel = q4 == 1 ? 0x07060302u : 0x05040100u;
+        u32x4 f;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) f[m] = __builtin_amdgcn_perm(gw[2 * m + 1], gw[2 * m], sel);
+        if (q4 == 3) f = u32x4{gw[8], gw[8] & 0xffffu, 0u, 0u};
+        pf[i] = __builtin_bit_cast(f16x8, f);
+    };
+    // Per chunk: request the A fragment and the bias, then MFMA i (16 channels x 16 pixels, all three split products of all nine taps)
+    // and, two steps later, its finish.  Nine steps, placed every third filler slot of the first two stages of the previous chunk.
+    f16x8 afr;
+    f32x4 bia, da, db;
+    auto fin = [&](const f32x4& d, int i, int buf) {
+        f32x4 v;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) v[r] = __builtin_amdgcn_fmed3f(d[r], 0.f, lim[i]);
+        typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+        f16x4 hi, lo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            hi[r] = (_Float16)v[r];
+            lo[r] = (_Float16)(v[r] - (float)hi[r]);
+        }
+        // Written as asm: for a C++ store without alias-scope metadata hipcc's waitcnt pass assumes it may alias the in-flight LDS-DMA
+        // writes (the weight ring) and puts `s_waitcnt vmcnt(0)` in front of it -- a full drain of the DMA queue once per finish.
+        // The halo buffers and the ring are disjoint; the writes are ordered before their readers by the `lgkmcnt(0)` + barrier that
+        // opens every stage.  (s_in is the start of the workgroup's LDS: offset = byte address.)
+        const int a_hi = wadr[i], a_lo = wadr[i] ^ 16;
+        const unsigned long long d_hi = __builtin_bit_cast(unsigned long long, hi), d_lo = __builtin_bit_cast(unsigned long long, lo);
+        if (buf == 0) {
+            asm volatile("ds_write_b64 %0, %1" ::"v"(a_hi), "v"(d_hi) : "memory");
+            asm volatile("ds_write_b64 %0, %1" ::"v"(a_lo), "v"(d_lo) : "memory");
+        } else {
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a_hi), "v"(d_hi), "n"(IN_SZ * 16) : "memory");
+            asm volatile("ds_write_b64 %0, %1 offset:%2" ::"v"(a_lo), "v"(d_lo), "n"(IN_SZ * 16) : "memory");
+        }
+    };
+    auto p_step = [&](int pos, int chn, int buf) {
+        switch (pos) {
+            case 0:
+                afr = __builtin_bit_cast(f16x8, s_a[chn * 64 + fresh_lane()]);
+                bia = *reinterpret_cast<const f32x4*>(s_b1 + chn * 16 + 4 * (fresh_lane() >> 4));
+                break;
+            case 1: da = mfma16x16(afr, pf[0], bia); break;
+            case 2: db = mfma16x16(afr, pf[1], bia); break;
+            case 3: fin(da, 0, buf); da = mfma16x16(afr, pf[2], bia); break;
+            case 4: fin(db, 1, buf); db = mfma16x16(afr, pf[3], bia); break;
+            case 5: fin(da, 2, buf); da = mfma16x16(afr, pf[4], bia); break;
+            case 6: fin(db, 3, buf); break;
+            case 7: fin(da, 4, buf); break;
+            default: break;
+        }
+    };
+    static_assert(NF == 5, "p_step is written out for five pixel groups per wave");
+
+    int w_off[NWA];  // weight pieces NWA wu .. NWA wu + NWA - 1 of a stage: LDS slots [WLP j, WLP j + WLP)
+#pragma unroll
+    for (int i = 0; i < NWA; ++i) {
+        const int g = (wu * NWA + i) * WLP + min(lane, WLP - 1), row = g >> 2, tl = row >> 6, n = row & 63;
+        w_off[i] = ((tl * p.CoutPad + n) * 4 + ((g & 3) ^ ((n >> 2) & 3))) * 16;
+    }
+    auto dma_w = [&](int c, int ky, int slot, int i) {
+        const int soff = (((c * 9 + 3 * ky) * p.CoutPad) * 4) * 16;
+        if (lane < WLP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, s_w + slot * WS + (wu * NWA + i) * WLP, 16, w_off[i], soff, 0, 0);
+    };
+
+    const int wy0 = (wu / WX) * 4, wx0 = (wu % WX) * 16;
+    const int i32 = lane & 31, h = lane >> 5;
+    f32x16 acc[2][2];
+    const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
+    int b_hi[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) b_hi[kx] = (P0 + kx) * 4 + ((2 * h) ^ (((P0 + kx) >> 2) & 3));
+    const int a_hi = i32 * 4 + ((2 * h) ^ ((i32 >> 2) & 3));
+
+    f16x8 fr[2][8];
+    auto read_frag = [&](int set, int buf, int slot, int ky, int kx, int i) {
+        const f16x8* si = reinterpret_cast<const f16x8*>(s_in + buf * IN_SZ) + ky * PW * 4;
+        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w + slot * WS) + kx * 64 * 4;
+        const int bx = b_hi[kx] ^ ((ky & 1) << 1);
+        switch (i) {
+            case 0: fr[set][0] = sw[a_hi]; break;
+            case 1: fr[set][1] = si[bx]; break;
+            case 2: fr[set][2] = si[bx + 2 * PW * 4]; break;
+            case 3: fr[set][3] = sw[a_hi + 32 * 4]; break;
+            case 4: fr[set][4] = si[bx ^ 1]; break;
+            case 5: fr[set][5] = si[(bx ^ 1) + 2 * PW * 4]; break;
+            case 6: fr[set][6] = sw[a_hi ^ 1]; break;
+            default: fr[set][7] = sw[(a_hi ^ 1) + 32 * 4]; break;
+        }
+    };
+
+    int id = blockIdx.x;
+    if (id >= total) return;
+    Tile cur = tile_of(id);
+    // prologue: gray tile -> s_g[0]; conv1a chunk 0 -> halo buffer 0; weight stages 0..2 -> slots 0..2
+    {
+        const __amdgpu_buffer_rsrc_t rs = gray_rsrc(cur);
+#pragma unroll
+        for (int j = 0; j < NGL; ++j) gray_load(rs, cur, j);
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int i = 0; i < NWA; ++i) dma_w(0, ky, ky, i);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread reads back what its own wave's DMA wrote
+        gray_store(0);
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();  // gray tile, A fragments, bias tables
+#pragma unroll
+    for (int i = 0; i < NF; ++i) {
+        build_a(i, 0, cur);
+        build_b(i);
+    }
+#pragma unroll
+    for (int pos = 0; pos <= 7; ++pos) p_step(pos, 0, 0);
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) read_frag(0, 0, 0, 0, 0, i);
+
+    int sidx = 0, gb = 0;
+    bool e_now = false, e_prev = false;
+    for (;;) {
+        const bool more = id + (int)gridDim.x < total;
+        const Tile nxt = tile_of(more ? id + (int)gridDim.x : id);
+        const __amdgpu_buffer_rsrc_t rs_g = gray_rsrc(nxt);
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+        auto chunk = [&](auto c_c) {
+            constexpr int C = decltype(c_c)::value, PAR = C & 1;
+            const bool has_next = C < 3 || more;        // the chunk after this one exists
+            constexpr int NC = (C + 1) & 3;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                // my VMEM instructions up to the stage before last are done (issued since: the previous stage's and, around a tile
+                // boundary, the E output stores), then everyone's
+                if (ky == 0) {
+                    if (C == 1) {   // previous stage (0,2): weight pieces + the gray loads of the next tile
+                        if (more) wait_vm_c<NWA + NGL>(); else wait_vm_c<NWA>();
+                    } else if (e_now) wait_vm_c<NWA + E>();
+                    else wait_vm_c<NWA>();
+                } else if (!has_next) {
+                    wait_vm_c<0>();
+                } else if (ky == 1 && e_prev) {
+                    wait_vm_c<NWA + E>();
+                } else {
+                    wait_vm_c<NWA>();
+                }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                __builtin_amdgcn_s_barrier();
+                e_prev = e_now;
+                e_now = false;
+                const int slot = sidx & 3, slot1 = (sidx + 1) & 3, slot3 = (sidx + 3) & 3;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int T = 3 * ky + kx, S = (T + PAR) & 1;
+                    int fslot = 0;
+                    // fillers of tap kx: slots 0-7 the fragment reads of the next tap; slots 2, 5, 8, 11 are the 24 conv1a slots of the first two
+                    // stages: every third one runs a step of the next chunk's conv1a (request, five MFMAs, five finishes); in the third stage of
+                    // chunk 2 the same slots build the next tile's five B fragments (two halves each); slots 9, 10 the VMEM work: weight pieces of
+                    // the stage three ahead (class A: taps 0, 0, 1) and, in the third stage of chunk 0, the six gray-tile loads; the gray store in
+                    // the third stage of chunk 1
+                    auto filler = [&]() {
+                        const int f = fslot++;
+                        if (f < 8) {
+                            if (T < 8) read_frag(1 - S, PAR, kx == 2 ? slot1 : slot, (T + 1) / 3, (T + 1) % 3, f);
+                            else read_frag(1 - S, 1 - PAR, slot1, 0, 0, f);
+                        }
+                        if (f == 2 || f == 5 || f == 8 || f == 11) {
+                            const int sl = kx * 4 + (f - 2) / 3;  // 0..11 inside the stage
+                            if (ky < 2) {
+                                const int s24 = ky * 12 + sl;
+                                if (has_next && s24 % 3 == 0) p_step(s24 / 3, NC, 1 - PAR);
+                            } else if (C == 2 && more && sl < 2 * NF) {
+                                if (sl & 1) build_b(sl >> 1);
+                                else build_a(sl >> 1, gb ^ 1, nxt);
+                            }
+                        }
+                        if (f == 9 || f == 10) {
+                            const int d = kx * 2 + (f - 9);  // 0..5
+                            if (d < NWA && has_next) dma_w(NC, ky, slot3, d);
+                            if (C == 0 && ky == 2 && more) gray_load(rs_g, nxt, d);
+                            if (C == 1 && ky == 2 && d == 0 && more) gray_store(gb ^ 1);
+                        }
+                        PIN();
+                    };
+                    PIN();
+                    acc[0][0] = mfma16(fr[S][0], fr[S][1], acc[0][0]); filler();
+                    acc[0][1] = mfma16(fr[S][0], fr[S][2], acc[0][1]); filler();
+                    acc[1][0] = mfma16(fr[S][3], fr[S][1], acc[1][0]); filler();
+                    acc[1][1] = mfma16(fr[S][3], fr[S][2], acc[1][1]); filler();
+                    acc[0][0] = mfma16(fr[S][0], fr[S][4], acc[0][0]); filler();
+                    acc[0][1] = mfma16(fr[S][0], fr[S][5], acc[0][1]); filler();
+                    acc[1][0] = mfma16(fr[S][3], fr[S][4], acc[1][0]); filler();
+                    acc[1][1] = mfma16(fr[S][3], fr[S][5], acc[1][1]); filler();
+                    acc[0][0] = mfma16(fr[S][6], fr[S][1], acc[0][0]); filler();
+                    acc[0][1] = mfma16(fr[S][6], fr[S][2], acc[0][1]); filler();
+                    acc[1][0] = mfma16(fr[S][7], fr[S][1], acc[1][0]); filler();
+                    acc[1][1] = mfma16(fr[S][7], fr[S][2], acc[1][1]); filler();
+                }
+                ++sidx;
+            }
+        };
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+        {
+            const int ln = fresh_lane(), hh = ln >> 5;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 bv = *reinterpret_cast<const f32x4*>(s_bias + mt * 32 + 8 * j + 4 * hh);
+#pragma unroll
+                    for (int nt = 0; nt < 2; ++nt) {
+                        acc[mt][nt][4 * j] += bv[0]; acc[mt][nt][4 * j + 1] += bv[1];
+                        acc[mt][nt][4 * j + 2] += bv[2]; acc[mt][nt][4 * j + 3] += bv[3];
+                    }
+                }
+            const int img_bytes = (p.H >> 1) * (p.W >> 1) * p.Cout * 4;
+            BufStore st{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)cur.b * img_bytes, 0, img_bytes, 0x00020000)};
+            epilogue_sh8_st<true>(acc, st, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, 0, ln);
+            e_now = true;
+        }
+        if (!more) break;
+        cur = nxt;
+        gb ^= 1;
+        id += gridDim.x;
+    }
+#endif
+}
+
 // conv1a writing SH8: 8 lanes per pixel, 8 output channels each (one hi + one lo 16-byte piece).
 __global__ __launch_bounds__(256) void conv1a_sh8_kernel(const Conv1aArgs p) {
     __shared__ float s_w[64 * 9 + 64 * 3];
@@ -1349,9 +1715,8 @@ void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
     // than one 8-wave workgroup per CU on the 240x320 and 120x160 maps.
     const bool generic = !(a.relu && !a.out_f32 && !a.post_scale);  // BatchNorm affine / fp32 output / no ReLU
     // Hot layout (ReLU, SH8 out): the LDS-DMA kernel, 16x32 or 32x16 pixel tiles, one 8-wave workgroup per CU.
-    // MG_CONV_STAGED=1 keeps the register-staged kernel below for A/B timing.
-    const char* env_staged = getenv("MG_CONV_STAGED");
-    const bool staged_only = env_staged && env_staged[0] == '1';
+    // a.staged (debug request "sp.conv_staged", tests/test_gpu_conv_dma.py) keeps the register-staged kernel below.
+    const bool staged_only = a.staged != 0;
     const long long out_img_bytes = (long long)(a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W) * a.Cout * 4;
     if (!generic && !staged_only && a.Cin % 32 == 0 && a.Cout % 4 == 0 && a.Cout <= CONV_DMA_MAXC && out_img_bytes < (1ll << 31) &&
         (!a.pool || (a.H % 2 == 0 && a.W % 2 == 0))) {
@@ -1387,16 +1752,13 @@ void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
 void launch_conv1ab_f16x3(const ConvF16Args& a, const Conv1aArgs& c1, hipStream_t s) {
     const long long items = (long long)((a.H + 15) / 16) * ((a.W + 31) / 32) * a.B;  // Cout = 64: one cout slice
     dim3 grid((unsigned)std::min<long long>(items, cu_count()));                     // persistent, one workgroup per CU (135 KB of LDS)
-    const char* env_staged = getenv("MG_CONV_STAGED");
-    const bool staged_only = env_staged && env_staged[0] == '1';
     const long long out_img_bytes = (long long)(a.H / 2) * (a.W / 2) * a.Cout * 4;
-    // conv1ab_dma_kernel (conv1a as fillers between the MFMAs, weights by LDS-DMA) is bit-identical to the register-staged kernel;
-    // MG_CONV1AB_DMA=0 selects the latter for A/B timing
-    const char* env_dma = getenv("MG_CONV1AB_DMA");
-    const bool want_dma = !(env_dma && env_dma[0] == '0');
-    if (want_dma && !staged_only && !a.post_scale && !c1.post_scale && a.Cout == 64 && a.H % 2 == 0 && a.W % 2 == 0 && out_img_bytes < (1ll << 31) &&
+    // a.staged (debug requests "sp.conv_staged" / "sp.conv1ab_staged"): 1 = the register-staged kernel (conv1a in fp32 on the VALU),
+    // 2 = round 2's LDS-DMA kernel with conv1a as VALU fillers (A/B timing of the round-3 change)
+    if (a.staged != 1 && !a.post_scale && !c1.post_scale && a.Cout == 64 && a.H % 2 == 0 && a.W % 2 == 0 && out_img_bytes < (1ll << 31) &&
         (long long)c1.C * c1.H * c1.W * 4 < (1ll << 31)) {
-        hipLaunchKernelGGL(conv1ab_dma_kernel, grid, dim3(CT), 0, s, a, c1);
+        if (a.staged == 2) hipLaunchKernelGGL(conv1ab_dma_kernel, grid, dim3(CT), 0, s, a, c1);
+        else hipLaunchKernelGGL(conv1ab_mfma_kernel, grid, dim3(CT), 0, s, a, c1);
         return;
     }
     if (a.post_scale) hipLaunchKernelGGL(conv1ab_f16x3_kernel<true>, grid, dim3(CT), 0, s, a, c1);

@@ -7,6 +7,14 @@
 // K advances in stages of 32; both operands are staged in LDS as [row][32 + 4 pad] floats (144-byte
 // rows = 9 x 16 B, so ds_read_b128 by 16 consecutive rows is conflict-free) and double-buffered with a
 // register prefetch, one barrier per stage.  Each ds_read_b128 feeds four MFMAs (common.h: mma_k8).
+//
+// PRECISE (GemmArgs::precise; LightGlue's final projection and similarity, lightglue.py:273-281, both arithmetic modes): the fp32
+// MFMA chain restarts from zero at every 32-deep K stage and the stage sums are added up in float64; bias and scale are applied in
+// float64 and the result is rounded to fp32 once.  An entry of log_assignment is 2 sim - lse_row - lse_col: with |sim| ~ 1e2 an
+// error of three fp32 ulps of sim is already north_star's whole 1e-4, and one 256-term fp32 chain (let alone 22-bit split-fp16
+// operands) does not keep that -- measured against the float64 oracle the f16x3 similarity put log_assignment 3.5x further from
+// the exact value than the fp32 CPU path, the single-chain fp32 MFMA 1.2-2x (gpurun_out/r03_a_tests.log).  Eight 32-term chains +
+// float64 sums leave ~0.3 ulp of sim.  Cost: the two GEMMs are 26 of the step's 5900 GFLOP.
 #include "common.h"
 #include "kernels.h"
 
@@ -14,8 +22,8 @@ namespace {
 
 constexpr int BM = 128, BN = 128, BK = 32, LDT = 36;
 
-template <bool W_ROWMAJOR>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
+template <bool W_ROWMAJOR, bool PRECISE>
+__global__ __launch_bounds__(256, PRECISE ? 1 : 2) void gemm_kernel(const GemmArgs p) {
     __shared__ __attribute__((aligned(16))) float smem[2][(BM + BN) * LDT];
 
     const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
@@ -35,6 +43,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
+    double dacc[PRECISE ? 2 : 1][PRECISE ? 2 : 1][PRECISE ? 16 : 1];
+    if (PRECISE) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) dacc[PRECISE ? i : 0][PRECISE ? j : 0][PRECISE ? r : 0] = 0.0;
+    }
     f32x4 ra[4], rw[4];
     const int nk = p.K / BK;
 
@@ -110,6 +127,17 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             mma_k8(a1, b0, acc[1][0]);
             mma_k8(a1, b1, acc[1][1]);
         }
+        if (PRECISE) {  // close this stage's fp32 chains: float64 running sums, fresh accumulators
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        dacc[PRECISE ? i : 0][PRECISE ? j : 0][PRECISE ? r : 0] += (double)acc[i][j][r];
+                        acc[i][j][r] = 0.f;
+                    }
+        }
         if (kt + 1 < nk) store_stage(buf ^ 1);
         __syncthreads();
     }
@@ -128,7 +156,15 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + mi * 32 + acc_row(r, lane);
                 const bool row_ok = row < p.M;
-                float v = acc[mi][ni][r] + bias;
+                float v;
+                if (PRECISE) {  // bias and scale in float64, one rounding
+                    double d = dacc[PRECISE ? mi : 0][PRECISE ? ni : 0][PRECISE ? r : 0] + (double)bias;
+                    if (col < p.scale_cols) d *= (double)p.scale;
+                    v = (float)d;
+                    if (row_ok && col_ok) C[(long long)row * p.ldc + col] = v;
+                    continue;
+                }
+                v = acc[mi][ni][r] + bias;
                 if (p.rotary_cols > 0) {  // lightglue.py:36-43 on adjacent feature pairs (2i,2i+1)
                     const float partner = __shfl_xor(v, 1);
                     if (col < p.rotary_cols) {
@@ -154,8 +190,11 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs p) {
 
 void launch_gemm(const GemmArgs& a, hipStream_t s) {
     dim3 grid((a.M + BM - 1) / BM, (a.N + BN - 1) / BN, a.batch);
-    if (a.w_rowmajor)
-        hipLaunchKernelGGL(gemm_kernel<true>, grid, dim3(256), 0, s, a);
+    if (a.precise) {  // plain C = scale (A W^T + bias): no rotary / ReLU / affine / residual in this form
+        if (a.w_rowmajor) hipLaunchKernelGGL((gemm_kernel<true, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((gemm_kernel<false, true>), grid, dim3(256), 0, s, a);
+    } else if (a.w_rowmajor)
+        hipLaunchKernelGGL((gemm_kernel<true, false>), grid, dim3(256), 0, s, a);
     else
-        hipLaunchKernelGGL(gemm_kernel<false>, grid, dim3(256), 0, s, a);
+        hipLaunchKernelGGL((gemm_kernel<false, false>), grid, dim3(256), 0, s, a);
 }

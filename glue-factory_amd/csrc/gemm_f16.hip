@@ -24,6 +24,12 @@
 
 namespace {
 
+// timing experiments of DESIGN.md section 4 (phase ablation): build a second library with -DMG_GEMM_EXP=1 (no stores) / 2 (no K loop);
+// results are wrong by design, the shipped library is built without it
+#ifndef MG_GEMM_EXP
+#define MG_GEMM_EXP 0
+#endif
+constexpr int GEMM_EXP = MG_GEMM_EXP;
 constexpr int TN = 256, BK = 16;  // 2 (feature halves) x TOKW (token groups) waves, each 128 features x 64 tokens
 constexpr int RS = 3;             // ring slots per operand: stage k+3 is issued into the slot stage k just left
 constexpr int TSLOTS = RS, WSLOTS = RS;
@@ -153,7 +159,7 @@ __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16
         else if (i < 8) bl[set][i - 6] = st[lane_lo + (i - 6) * 32 * 4];
         else al[set][i - 8] = sw[lane_lo + (i - 8) * 32 * 4];
     };
-    if (nk > 0 && !(p.debug & 2)) {
+    if (nk > 0 && !(GEMM_EXP & 2)) {
         // stage 0 landed (mine): all but the younger stages' pieces (NPW per stage)
         if (npro >= 3) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * NPW) : "memory");
         else if (npro == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NPW) : "memory");
@@ -194,7 +200,7 @@ __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16
 #pragma unroll
             for (int tt = 0; tt < 2; ++tt) { acc[ft][tt] = mfma16(al[S][ft], bh[S][tt], acc[ft][tt]); filler(); }
     };
-    if (!(p.debug & 2)) {
+    if (!(GEMM_EXP & 2)) {
 #pragma unroll 1
         for (int kt = 0; kt < nk; kt += 2) {
             stage(std::integral_constant<int, 0>{}, kt);
@@ -285,13 +291,13 @@ __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16
                     u32x4 q0 = __builtin_bit_cast(u32x4, f32x4{w[0], w[1], w[2], w[3]}), q1 = __builtin_bit_cast(u32x4, f32x4{w[4], w[5], w[6], w[7]});
                     u32x4 q2 = __builtin_bit_cast(u32x4, f32x4{w[8], w[9], w[10], w[11]}), q3 = __builtin_bit_cast(u32x4, f32x4{w[12], w[13], w[14], w[15]});
                     quad_transpose(q0, q1, q2, q3, ql);
-                    if (!(p.debug & 1)) {
+                    if (!(GEMM_EXP & 1)) {
 #pragma unroll
                         for (int sidx = 0; sidx < 4; ++sidx)
                             if (tq + sidx < p.M)
                                 *reinterpret_cast<u32x4*>(C + (long long)(tq + sidx) * p.ldc + fb + 4 * ql) = sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3;
                     }
-                } else if (C && tok_ok && !(p.debug & 1)) {
+                } else if (C && tok_ok && !(GEMM_EXP & 1)) {
                     float* o = C + tokc * p.ldc + fb;
 #pragma unroll
                     for (int j = 0; j < 16; ++j) o[j] = w[j];
@@ -306,7 +312,7 @@ __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16
                     u32x4 q2 = __builtin_bit_cast(u32x4, hi1), q3 = __builtin_bit_cast(u32x4, lo1);
                     quad_transpose(q0, q1, q2, q3, ql);
                     u32x4* ob = reinterpret_cast<u32x4*>(p.Cs) + z * (p.strideCs >> 2);
-                    if (!(p.debug & 1)) {
+                    if (!(GEMM_EXP & 1)) {
 #pragma unroll
                         for (int sidx = 0; sidx < 4; ++sidx)
                             if (tq + sidx < p.M)
@@ -346,15 +352,11 @@ __global__ __launch_bounds__(256) void from_sh8_kernel(const void* __restrict__ 
 }  // namespace
 
 void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
-    static const int dbg = getenv("MG_GEMM_DEBUG") ? atoi(getenv("MG_GEMM_DEBUG")) : 0;  // timing experiments only
     GemmF16Args a = a0;
-    a.debug = dbg;
-    // two 4-wave workgroups per CU (TOKW = 2) unless the problem is too small to give every CU two tiles anyway;
-    // MG_GEMM_TOKW=4 forces the 8-wave tile for A/B timing
-    static const int force_tokw = getenv("MG_GEMM_TOKW") ? atoi(getenv("MG_GEMM_TOKW")) : 0;
-    const int tokw = force_tokw == 4 ? 4 : 2;
-    // sweep on one box (profiles/r02_z notes in DESIGN.md): 0 / 1 / 2 / 3 / 5 -> qkv 1.081 / 1.058 / 1.033 / 1.025 / 1.090 ms per step
-    static const int stagger = getenv("MG_GEMM_STAGGER") ? atoi(getenv("MG_GEMM_STAGGER")) : 3;
+    // two 4-wave workgroups per CU (TOKW = 2; the 8-wave tile of round 1 measured 1-5 % slower)
+    constexpr int tokw = 2;
+    // second-placed workgroups start `stagger` sleeps late; sweep on one box: 0 / 1 / 2 / 3 / 5 -> qkv 1.081 / 1.058 / 1.033 / 1.025 / 1.090 ms per step
+    constexpr int stagger = 3;
     static int cus = 0;
     if (!cus) {
         int dev = 0;
@@ -370,8 +372,7 @@ void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
     const bool ragged = (a.N & 31) != 0;
 #define MG_GEMM_LAUNCH(RM, RG)                                                                                      \
     do {                                                                                                            \
-        if (tokw == 4) hipLaunchKernelGGL((gemm_f16x3_kernel<RM, RG, 4>), grid, dim3(512), 0, s, a);                  \
-        else hipLaunchKernelGGL((gemm_f16x3_kernel<RM, RG, 2>), grid, dim3(256), 0, s, a);                            \
+        hipLaunchKernelGGL((gemm_f16x3_kernel<RM, RG, 2>), grid, dim3(256), 0, s, a);                                 \
     } while (0)
     if (a.w_rowmajor) {
         if (ragged) MG_GEMM_LAUNCH(true, true);

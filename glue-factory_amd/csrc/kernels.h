@@ -32,6 +32,7 @@ struct GemmArgs {
     // batching (blockIdx.z): element strides
     int batch = 1;
     long long strideA = 0, strideW = 0, strideC = 0;
+    int precise = 0;  // fp32 chains of one 32-deep stage, stage sums / bias / scale in float64 (bias + scale epilogue only)
 };
 void launch_gemm(const GemmArgs& a, hipStream_t s);
 
@@ -74,6 +75,7 @@ struct ConvF16Args {
     int pool = 0;
     int relu = 1;
     int out_f32 = 0;
+    int staged = 0;              // debug requests only: 1 = register-staged kernels, 2 (conv1ab) = round 2's VALU-conv1a kernel
 };
 void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s);
 void launch_conv1a_sh8(const Conv1aArgs& a, hipStream_t s);
@@ -108,7 +110,6 @@ struct GemmF16Args {
     int ldr = 0;
     int batch = 1;
     long long strideA = 0, strideW = 0, strideC = 0, strideCs = 0;  // elements
-    int debug = 0;  // timing experiments: 1 = skip the stores, 2 = skip the main loop
     int stagger = 0, stagger_lo = 0, stagger_hi = 0;  // workgroups [lo, hi) sleep `stagger` x 8128 cycles before they start (set by the launcher)
 };
 void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s);

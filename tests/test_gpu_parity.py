@@ -341,7 +341,8 @@ def test_two_view_boat_golden(dev, golden, variant, precision):
     for k in ("keypoints0", "keypoints1"):
         assert torch.equal(ref[k], g[f"{variant}.{k}"])
     lgc = dict(filter_threshold=0.1)
-    TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat {variant}/{precision}", anchor=AN.TwoViewAnchor(data, W_sp, W_lg, spc, lgc))
+    host = lambda d: {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in d.items()}
+    TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat {variant}/{precision}", anchor=AN.TwoViewAnchor(host(data), W_sp, W_lg, spc, lgc))
     # shifted self-pair: genuine correspondences
     a = im0[:, :, 0:640, 0:800].contiguous()
     b = im0[:, :, 16:656, 24:824].contiguous()
@@ -350,7 +351,7 @@ def test_two_view_boat_golden(dev, golden, variant, precision):
     p = pipe(data)
     ref = O.two_view_forward({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in data.items()}, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
     assert torch.equal(ref["keypoints0"], g[variant + ".shift.keypoints0"]) and torch.equal(ref["matches0"], g[variant + ".shift.matches0"])
-    r = TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat-shift {variant}/{precision}", anchor=AN.TwoViewAnchor(data, W_sp, W_lg, spc, lgc))
+    r = TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat-shift {variant}/{precision}", anchor=AN.TwoViewAnchor(host(data), W_sp, W_lg, spc, lgc))
     assert (ref["matches0"] > -1).sum() > 100 and r["m0"]["compared"] > 500
 
 
