@@ -66,7 +66,8 @@ class TwoViewAnchor:
     """fp64 SuperPoint + LightGlue on one two-view input.  The dense stage (the expensive part) runs once; `at()` then evaluates the
     sparse stage and the matcher in fp64 on ANY keypoint decisions -- the HIP path's own or the fp32 oracle's."""
 
-    def __init__(self, data, W_sp, W_lg, sp_conf, lg_conf):
+    def __init__(self, data, W_sp, W_lg, sp_conf, lg_conf, matcher=None):
+        self.matcher = matcher  # the matcher's oracle forward (default LightGlue)
         self.data = O.cast({k: v for k, v in data.items() if k in ("view0", "view1")}, F64)
         self.W_sp, self.W_lg = O.cast(W_sp, F64), O.cast(W_lg, F64)
         self.sp_conf, self.lg_conf = dict(sp_conf), dict(lg_conf)
@@ -86,7 +87,7 @@ class TwoViewAnchor:
         for i in ("0", "1"):
             data["view" + i] = {k: v[b:b + 1] for k, v in self.data["view" + i].items()}
         dense = [tuple(t[b:b + 1] for t in d) for d in self.dense]
-        return O.two_view_forward(data, self.W_sp, self.W_lg, self.sp_conf, self.lg_conf, force_yx=yx, dense=dense)
+        return O.two_view_forward(data, self.W_sp, self.W_lg, self.sp_conf, self.lg_conf, force_yx=yx, dense=dense, matcher=self.matcher)
 
 
 def matcher_floats(fwd, p, ref32, data, W, name, keys, conf=None, replay=None, scores=(("log_assignment", "matching_scores0", "matching_scores1"),),

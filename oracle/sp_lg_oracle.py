@@ -505,12 +505,13 @@ def lightglue_forward(data, W, collect_layers=(), replay=None, **conf):
 # --------------------------------------------------------------------------
 # Two-view composite
 # --------------------------------------------------------------------------
-def two_view_forward(data, W_sp, W_lg, sp_conf, lg_conf, with_maps=False, force_yx=None, dense=None):
+def two_view_forward(data, W_sp, W_lg, sp_conf, lg_conf, with_maps=False, force_yx=None, dense=None, matcher=None):
     """two_view_pipeline.py:62-90 -- extractor per view, keys suffixed 0/1, then the matcher.
     `with_maps` also returns the score maps behind the keypoint decisions (`_nms_scores0/1`, `_heatmap0/1`) for
     the tie-aware index checks of the tests; they are not part of the reference's pred dict.
     `force_yx` = (list per image of view 0, list per image of view 1) of (n,2) (y,x) pixels, `dense` = (dense stage of view 0,
-    of view 1): see superpoint_forward."""
+    of view 1): see superpoint_forward.  `matcher`: the matcher's forward (default lightglue_forward; superglue_forward for
+    BASELINE.json configs[3]) -- called as matcher({**data, **pred}, W_lg, **lg_conf)."""
     pred, maps = {}, {}
     for i in ("0", "1"):
         p = superpoint_forward(data["view" + i], W_sp, force_yx=None if force_yx is None else force_yx[int(i)],
@@ -520,11 +521,12 @@ def two_view_forward(data, W_sp, W_lg, sp_conf, lg_conf, with_maps=False, force_
         if sp_conf.get("variant") == "open":
             pred["heatmap" + i] = p["heatmap"]
         maps["_nms_scores" + i], maps["_heatmap" + i] = p["nms_scores"], p["heatmap"]
-    lg = lightglue_forward({**data, **pred}, W_lg, **lg_conf)
+    lg = (matcher or lightglue_forward)({**data, **pred}, W_lg, **lg_conf)
     pred.update({k: v for k, v in lg.items() if not k.startswith("_")})
     if with_maps:
         pred.update(maps)
-        pred["_sim"] = lg["_sim"]
+        if "_sim" in lg:
+            pred["_sim"] = lg["_sim"]
     return pred
 
 
