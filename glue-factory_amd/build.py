@@ -21,8 +21,12 @@ SOURCES = ["api.hip", "gemm.hip", "conv.hip", "conv_f16.hip", "gemm_f16.hip", "a
 # exact product) next to a separately rounded fp32 product: the hi half written by split8 and the hi half its lo was computed
 # against then differed in the double-rounding cases, an error of one fp16 ulp (2^-11) in a value that should carry 22 bits
 # (to_sh8_kernel; caught by tests/test_gpu_f16x3_range.py).
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function",
-         "-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
+# attention_f16.hip is the one file built WITH the mix instructions: its probability split writes v_fma_mixlo/hi_f16 by hand (x - hi read
+# straight from the fp16 half: 1.5 instead of 3 VALU instructions per element of a VALU-issue-bound loop); the only product that
+# feeds a conversion there (o * 1/l in the epilogue) passes through inline asm first, so it exists as a rounded fp32 register.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
+NO_MIX = ["-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
+MIX_ON = {"attention_f16.hip"}
 NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # Two files keep the feature on: conv_f16.hip (the assembler rejects its inline-asm v_pk_fma_f32 on real register pairs once the
 # feature is off) and ffn_f16.hip (without it the LayerNorm / GELU phase costs 0.8 ms per step).  What is ENFORCED, on the device
@@ -54,7 +58,7 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         # -save-temps=obj leaves the device assembly of exactly this compilation beside the object (scanned below, then removed)
-        cmd = [hipcc, *FLAGS, *([] if src in PK_ON else NO_PK), "-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *([] if src in MIX_ON else NO_MIX), *([] if src in PK_ON else NO_PK), "-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -29,14 +29,19 @@ constexpr float RESCALE_THR = 8.f;  // in log2 units
 constexpr float P_SHIFT = 7.f;
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 
-// x (>= 0, fp16 range) -> packed (hi, lo) halves of a pair: hi = x truncated to 11 significant bits (a mask: exact in
-// fp16 above the subnormal zone), lo = fp16(x - hi) rounded to nearest (v_cvt_pk_f16_f32) -> 22 bits, unbiased.
+// x (>= 0, fp16 range) -> packed (hi, lo) halves of a pair: hi = x rounded toward zero to fp16 (v_cvt_pkrtz: truncation to 11
+// significant bits), lo = fp16(x - hi) rounded to nearest -> 22 bits, unbiased.  Round 3: 1.5 VALU instructions per element instead
+// of 3 (mask, subtract, two packed conversions): the mixed-precision FMA reads the fp16 hi half directly, evaluates x - hi in fp32
+// (exact) and writes the rounded fp16 result into one half of the destination -- of the 281 VALU instructions a full key tile executes
+// in this VALU-issue-bound loop (branch-aware count of the ISA, profiles/r03_attention_isa.txt), 96 were the split; now 239.  Written as asm: left to itself hipcc converts hi back to fp32 first (no gain), and the
+// translation unit is the only one built with the mix instructions enabled (build.py; DESIGN.md section 4, hazard 2, is about
+// COMPILER-chosen v_fma_mixlo on a product -- the epilogue below pins its products in fp32 registers for that reason).
 __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, unsigned& lo) {
-    const float h0 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x0) & 0xFFFFE000u);
-    const float h1 = __builtin_bit_cast(float, __builtin_bit_cast(unsigned, x1) & 0xFFFFE000u);
-    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(h0, h1));
-    const f16x2 l = {(_Float16)(x0 - h0), (_Float16)(x1 - h1)};
-    lo = __builtin_bit_cast(unsigned, l);
+    hi = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(x0, x1));
+    asm("v_fma_mixlo_f16 %0, %1, -1.0, %2 op_sel:[0,0,0] op_sel_hi:[1,0,0]\n\t"
+        "v_fma_mixhi_f16 %0, %1, -1.0, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]"
+        : "=&v"(lo)
+        : "v"(hi), "v"(x0), "v"(x1));
 }
 
 __global__ __launch_bounds__(AT, 2) void attention_f16x3_kernel(const AttnF16Args p) {
@@ -191,7 +196,7 @@ __global__ __launch_bounds__(AT, 2) void attention_f16x3_kernel(const AttnF16Arg
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 float a0 = o[qt][dt][e] * inv, b0 = o[qt][dt][8 + e] * inv, a1 = o[qt][dt][4 + e] * inv, b1 = o[qt][dt][12 + e] * inv;
-                half_swap(a0, b0);
+                half_swap(a0, b0);  // (asm: the products above are fp32 registers here, never fused into the conversions of split8)
                 half_swap(a1, b1);
                 w[e] = a0; w[4 + e] = b0; w[8 + e] = a1; w[12 + e] = b1;
             }

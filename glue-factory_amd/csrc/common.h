@@ -78,6 +78,17 @@ __device__ __forceinline__ void mma3x2(const f16x8 ah, const f16x8 al, const f16
     c0 = mfma16(al, bh0, c0);
     c1 = mfma16(al, bh1, c1);
 }
+// acc * winv + bias with winv a wave-uniform power of two (the scaling of uploaded weights, api.hip: pow2_scale): ONE scalar-operand
+// v_fma_f32, written as asm so that no translation unit turns runs of them into v_pk_fma_f32 with an op_sel broadcast of the scalar
+// (build.py / pk_scan.py keep those out of kernels with MFMAs).  hipcc's hazard recognizer does not look inside asm statements: an
+// accumulator an MFMA has just written must not be read by this instruction before the MFMA has retired -- every epilogue that
+// starts with it executes mfma_results_guard() first (both are volatile, so they keep their order).
+__device__ __forceinline__ float fma_winv(float acc, float winv, float bias) {
+    float r;
+    asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "s"(winv), "v"(bias));
+    return r;
+}
+__device__ __forceinline__ void mfma_results_guard() { asm volatile("s_nop 15\n\ts_nop 15" ::: "memory"); }
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 __device__ __forceinline__ void split8(const f32x8 v, f16x8& hi, f16x8& lo) {
 #pragma unroll

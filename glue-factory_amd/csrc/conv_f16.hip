@@ -164,6 +164,7 @@ template <bool GENERIC>
 __device__ __forceinline__ void conv_epilogue(const ConvF16Args& p, f32x16 (&acc)[2][2], const float* sb, int b, int yw, int xw, int n0, int lane) {
     const int i32 = lane & 31, h = lane >> 5;
     if (sb) {
+        mfma_results_guard();
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -171,8 +172,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvF16Args& p, f32x16 (&acc
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + mt * 32 + 8 * j + 4 * h);
 #pragma unroll
                 for (int nt = 0; nt < 2; ++nt) {
-                    acc[mt][nt][4 * j] += bv[0]; acc[mt][nt][4 * j + 1] += bv[1];
-                    acc[mt][nt][4 * j + 2] += bv[2]; acc[mt][nt][4 * j + 3] += bv[3];
+                    acc[mt][nt][4 * j] = fma_winv(acc[mt][nt][4 * j], p.winv, bv[0]); acc[mt][nt][4 * j + 1] = fma_winv(acc[mt][nt][4 * j + 1], p.winv, bv[1]);
+                    acc[mt][nt][4 * j + 2] = fma_winv(acc[mt][nt][4 * j + 2], p.winv, bv[2]); acc[mt][nt][4 * j + 3] = fma_winv(acc[mt][nt][4 * j + 3], p.winv, bv[3]);
                 }
             }
     }
@@ -691,6 +692,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
         // epilogue: bias (LDS table of the whole layer), ReLU, pool, SH8 -- E unconditional buffer stores per wave
         {
             const float* sb = s_bias + cur.n0;
+            mfma_results_guard();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -698,8 +700,8 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + mt * 32 + 8 * j + 4 * h);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        acc[mt][nt][4 * j] += bv[0]; acc[mt][nt][4 * j + 1] += bv[1];
-                        acc[mt][nt][4 * j + 2] += bv[2]; acc[mt][nt][4 * j + 3] += bv[3];
+                        acc[mt][nt][4 * j] = fma_winv(acc[mt][nt][4 * j], p.winv, bv[0]); acc[mt][nt][4 * j + 1] = fma_winv(acc[mt][nt][4 * j + 1], p.winv, bv[1]);
+                        acc[mt][nt][4 * j + 2] = fma_winv(acc[mt][nt][4 * j + 2], p.winv, bv[2]); acc[mt][nt][4 * j + 3] = fma_winv(acc[mt][nt][4 * j + 3], p.winv, bv[3]);
                     }
                 }
             const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
@@ -927,347 +929,6 @@ __global__ __launch_bounds__(CT, 2) void conv1ab_f16x3_kernel(const ConvF16Args 
         cur = nxt;
         id += gridDim.x;
     }
-}
-
-// conv1a + conv1b + pool on the stage machinery of conv3x3_dma_kernel (round 2).  Differences to the kernel above:
-//   * the weight rows of conv1b go through the same four-slot LDS-DMA ring, one barrier per filter row -- the two barriers
-//     and the register -> LDS weight copy per chunk are gone;
-//   * all eight waves multiply all the time; the conv1a outputs of the NEXT chunk (three halo pixels x eight channels per
-//     lane) are computed in twelve small steps (nine taps of the three pixels, three of bias / ReLU / split / LDS write)
-//     placed as fillers between the MFMAs of the first two stages of a chunk, every third MFMA, so they are in LDS one
-//     stage before the fragment prefetch of the next chunk needs them;
-//   * the gray tile of the next image tile is fetched during chunk 0 (six unconditional buffer loads per thread: a
-//     one-channel image is read three times so that the VMEM count does not depend on C), converted and stored into
-//     the second gray buffer during chunk 1, and used by the produce steps of chunk 3.
-// The accumulation orders (conv1a taps, conv1b products / taps / chunks) are those of conv1ab_f16x3_kernel: bit-identical.
-__global__ __launch_bounds__(512, 2) void conv1ab_dma_kernel(const ConvF16Args p, const Conv1aArgs c1) {
-#if defined(__HIP_DEVICE_COMPILE__)
-    constexpr int WX = 2, TH = 16, TW = 32;
-    constexpr int PW = ((TW + 2 + 7) / 16) * 16 + 8;
-    constexpr int NPIX = (TH + 2) * (TW + 2);
-    constexpr int IN_SZ = (TH + 2) * PW * 4;
-    constexpr int WS = 3 * 64 * 4, WR = 4, NWA = 2, WLP = WS / (8 * NWA);  // two 48-lane weight pieces per wave and stage
-    constexpr int E = 4;                              // pooled output: four stores per wave and tile
-    constexpr int NGL = 6;                            // gray-tile loads per thread and tile (2 pixels x 3 channels)
-    constexpr int GH = TH + 4, GW = TW + 4, GP = GW + 1, GSZ = ((GH * GP + 3) / 4) * 4;
-    static_assert(GH * GW <= 2 * 512, "two gray pixels per thread");
-    // ONE LDS array: [2 halo tiles][4 weight stages][2 gray tiles][conv1a taps + bias][conv1b bias][raw image values of the next gray tile]
-    __shared__ u32x4 s_all[2 * IN_SZ + WR * WS + 2 * GSZ / 4 + 10 * 64 / 4 + 64 / 4 + NGL * 512 / 4];
-    u32x4* const s_in = s_all;
-    u32x4* const s_w = s_all + 2 * IN_SZ;
-    float* const s_g = reinterpret_cast<float*>(s_all + 2 * IN_SZ + WR * WS);
-    float* const s_c1 = s_g + 2 * GSZ;                // [9 taps][64 ch] | bias
-    float* const s_bias = s_c1 + 10 * 64;
-    float* const s_raw = s_bias + 64;                 // [load j][thread]: written by LDS-DMA, read back by the same thread
-
-    const int t = threadIdx.x, lane = t & 63;
-    const int wu = __builtin_amdgcn_readfirstlane(t >> 6);
-    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
-    const int tiles = tiles_x * tiles_y, total = tiles * p.B;
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wt), 0, 0x7fffffff, 0x00020000);
-
-    struct Tile { int b, y0, x0; };
-    auto tile_of = [&](int id) {
-        int logical = id;
-        if ((total & 7) == 0) logical = (id & 7) * (total >> 3) + (id >> 3);
-        const int tl = logical % tiles;
-        return Tile{logical / tiles, (tl / tiles_x) * TH, (tl % tiles_x) * TW};
-    };
-
-    for (int i = t; i < 10 * 64; i += 512) {
-        const int k = i >> 6, ch = i & 63;
-        s_c1[i] = k < 9 ? c1.w[ch * 9 + k] : c1.bias[ch];
-    }
-    if (t < 64) s_bias[t] = t < p.Cout ? p.bias[t] : 0.f;
-
-    // gray tile (RGB -> gray as superpoint.py:204-206), zero outside the image: thread t owns tile pixels t and t + 512
-    // (the raw values travel global -> LDS by DMA and are converted a chunk later: held in registers across a chunk they were spilled)
-    const int HWb = c1.H * c1.W * 4;
-    auto gray_rsrc = [&](const Tile& tl) {
-        return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(c1.image) + (long long)tl.b * c1.C * c1.H * c1.W, 0, c1.C * HWb, 0x00020000);
-    };
-    auto gray_load = [&](const __amdgpu_buffer_rsrc_t& rs, const Tile& tl, int j) {  // load j of NGL: pixel j / 3, channel j % 3
-        const int ch = c1.C == 3 ? j % 3 : 0;
-        const int i = wu * 64 + fresh_lane() + 512 * (j / 3), gy = i / GW, gx = i - gy * GW;  // recomputed per load: nothing kept live
-        const int yy = tl.y0 + gy - 2, xx = tl.x0 + gx - 2;
-        const bool ok = i < GH * GW && (unsigned)yy < (unsigned)c1.H && (unsigned)xx < (unsigned)c1.W;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, s_raw + j * 512 + wu * 64, 4, ok ? (yy * c1.W + xx) * 4 : (int)0x80000000, ch * HWb, 0, 0);
-    };
-    auto gray_store = [&](int gb) {
-        const int tt = wu * 64 + fresh_lane();  // addresses recomputed here, not hoisted out of the tile loop (see p_tap)
-#pragma unroll
-        for (int k = 0; k < 2; ++k) {
-            const int i = tt + 512 * k, gy = i / GW, gx = i - gy * GW;
-            const float r0 = s_raw[(3 * k) * 512 + tt], r1 = s_raw[(3 * k + 1) * 512 + tt], r2 = s_raw[(3 * k + 2) * 512 + tt];
-            const float v = c1.C == 3 ? __fadd_rn(__fadd_rn(__fmul_rn(r0, 0.299f), __fmul_rn(r1, 0.587f)), __fmul_rn(r2, 0.114f)) : r0;
-            if (i < GH * GW) s_g[gb * GSZ + gy * GP + gx] = v;
-        }
-    };
-
-    // conv1a for one chunk: this wave's 8-channel group gg of the chunk, halo pixels hp0 + 256 i of the tile
-    const int gg = wu & 1, hp0 = (wu >> 1) * 64 + lane;
-    int gofs[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
-        const int hp = min(hp0 + 256 * i, NPIX - 1), py = hp / (TW + 2), px = hp - py * (TW + 2);
-        gofs[i] = py * GP + px;
-    }
-    // One pixel at a time (eight accumulators as four register pairs), fifteen steps per chunk: step st = pixel st / 5, part st % 5;
-    // parts 0-3 are two taps each, part 4 is the last tap + bias / ReLU / split / LDS write.  The LDS operands of step st + 1
-    // (tap rows of the table, gray values, bias) are requested at the end of step st, so no step waits for its own reads.
-    // The opaque asm statements keep hipcc from (i) hoisting the per-step address arithmetic out of the tile loop (hoisted, those ~60
-    // invariants were spilled -- and a scratch reload is a VMEM instruction, which would break the counted vmcnt waits) and
-    // (ii) sinking all nine taps of a pixel into the guarded store block of its last step (one 130-instruction VALU block
-    // between two MFMAs with every tap's weights preloaded into registers).
-    f32x2 o2[3][4];           // three pixels x eight channels (as four register pairs each)
-    f32x4 tw0[2], tw1[2];     // table row of a tap (this wave's eight channels): [tap parity]
-    f32x2 tg2[2][3];          // gray value of a tap as the register pair {g, g}, per pixel: [tap parity][pixel]
-    int c1v = gg * 8;  // this wave's channel offset inside a chunk, held in a VGPR so that the constants fold into ds_read offsets
-    asm volatile("" : "+v"(c1v));
-    // step k (0..9) requests the LDS operands of tap k (k == 9: the bias row): one table row serves the three pixels, so the
-    // conv1a phase reads 18 table rows + 27 gray pairs per chunk and wave (per-pixel steps read the table three times: at 256 B/clk
-    // the LDS then runs at ~85 % with the MFMA fragments and the produce stores)
-    unsigned ga[3];  // LDS byte addresses of the three pixels' gray windows, set at the first step of a chunk
-    auto p_issue = [&](int k, int chn, int gb) {
-        const int set = k & 1;
-        if (k == 0) {
-#pragma unroll
-            for (int i = 0; i < 3; ++i) {
-                int go = gofs[i];
-                asm volatile("" : "+v"(go));  // computed here, once per chunk: not hoisted out of the tile loop for all chunks / gray buffers
-                ga[i] = (unsigned)(size_t)(__attribute__((address_space(3))) const void*)(s_g + gb * GSZ + go);
-            }
-        }
-        if (k < 9) {
-            // the gray pairs first: these asm loads are not tracked by the compiler's s_waitcnt insertion, but LDS returns in order
-            // and every FMA also needs the table row requested AFTER them, which the compiler does wait for
-#pragma unroll
-            for (int i = 0; i < 3; ++i)
-                asm volatile("ds_read2_b32 %0, %1 offset0:%2 offset1:%2" : "=v"(tg2[set][i]) : "v"(ga[i]), "n"((k / 3) * GP + (k % 3)));
-        }
-        tw0[set] = *reinterpret_cast<const f32x4*>(&s_c1[k * 64 + chn * 16 + c1v]);
-        tw1[set] = *reinterpret_cast<const f32x4*>(&s_c1[k * 64 + chn * 16 + c1v + 4]);
-    };
-    // Same tap order and the same IEEE fma as the reference accumulation; v_pk_fma_f32 = two fmas per instruction.  The whole
-    // library is compiled WITHOUT hipcc's packed-fp32 code generation (build.py: -packed-fp32-ops): packed-fp32 instructions whose
-    // operand broadcast is expressed through op_sel / op_sel_hi (v_pk_fma_f32 ... op_sel:[0,1,0], what the compiler emits for
-    // {g, g}) returned wrong LOW halves, nondeterministically, whenever MFMAs were executing on the same SIMD -- here between this
-    // wave's own MFMAs (even conv1a channels wrong, never in the MFMA-free prologue, not cured by nops or waits), and in the GEMM
-    // epilogue once a second workgroup's MFMAs shared the SIMD (tests/test_gpu_determinism.py, tests/micro/diag_conv1ab_det.py).
-    // Packed FMAs on REAL register pairs, no op_sel, are clean (same tests), so these are written out as inline asm -- which also
-    // keeps hipcc from sinking all taps into the guarded store block of the last step.
-    const f32x2 zero2 = {0.f, 0.f};
-    auto p_tap = [&](int k) {
-        const int set = k & 1;
-        const f32x2 w[4] = {f32x2{tw0[set][0], tw0[set][1]}, f32x2{tw0[set][2], tw0[set][3]}, f32x2{tw1[set][0], tw1[set][1]}, f32x2{tw1[set][2], tw1[set][3]}};
-#pragma unroll
-        for (int i = 0; i < 3; ++i)
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-                if (k == 0) asm volatile("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(o2[i][c]) : "v"(w[c]), "v"(tg2[set][i]), "v"(zero2));
-                else asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(o2[i][c]) : "v"(w[c]), "v"(tg2[set][i]));
-            }
-    };
-    auto p_fin = [&](int i, int buf, const Tile& tl) {  // bias (row 9 -> tw0[1] | tw1[1]), ReLU, zero outside the image, SH8 pieces -> halo tile
-        int hp = hp0 + 256 * i;
-        asm volatile("" : "+v"(hp));
-        const int py = hp / (TW + 2), px = hp - py * (TW + 2);
-        const int yy = tl.y0 + py - 1, xx = tl.x0 + px - 1;
-        const bool inside = (unsigned)yy < (unsigned)c1.H && (unsigned)xx < (unsigned)c1.W;
-        f32x8 v;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            v[j] = inside ? fmaxf(o2[i][j >> 1][j & 1] + tw0[1][j], 0.f) : 0.f;
-            v[4 + j] = inside ? fmaxf(o2[i][2 + (j >> 1)][j & 1] + tw1[1][j], 0.f) : 0.f;
-        }
-        f16x8 hi, lo;
-        split8(v, hi, lo);
-        const int P = py * PW + px, sw4 = (P >> 2) & 3;
-        if (hp < NPIX) {
-            s_in[buf * IN_SZ + P * 4 + ((2 * gg) ^ sw4)] = __builtin_bit_cast(u32x4, hi);
-            s_in[buf * IN_SZ + P * 4 + ((2 * gg + 1) ^ sw4)] = __builtin_bit_cast(u32x4, lo);
-        }
-    };
-    // position 0: request tap 0; positions 1-9: multiply tap pos - 1 and request the next row (row 9 = bias); positions 10-12: finishes
-    auto p_step = [&](int pos, int chn, int gb, int buf, const Tile& tl) {
-        if (pos == 0) p_issue(0, chn, gb);
-        else if (pos <= 9) {
-            p_tap(pos - 1);
-            p_issue(pos, chn, gb);
-        } else if (pos <= 12) p_fin(pos - 10, buf, tl);
-    };
-
-    int w_off[NWA];  // weight pieces NWA wu .. NWA wu + NWA - 1 of a stage: LDS slots [WLP j, WLP j + WLP)
-#pragma unroll
-    for (int i = 0; i < NWA; ++i) {
-        const int g = (wu * NWA + i) * WLP + min(lane, WLP - 1), row = g >> 2, tl = row >> 6, n = row & 63;
-        w_off[i] = ((tl * p.CoutPad + n) * 4 + ((g & 3) ^ ((n >> 2) & 3))) * 16;
-    }
-    auto dma_w = [&](int c, int ky, int slot, int i) {
-        const int soff = (((c * 9 + 3 * ky) * p.CoutPad) * 4) * 16;
-        if (lane < WLP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, s_w + slot * WS + (wu * NWA + i) * WLP, 16, w_off[i], soff, 0, 0);
-    };
-
-    const int wy0 = (wu / WX) * 4, wx0 = (wu % WX) * 16;
-    const int i32 = lane & 31, h = lane >> 5;
-    f32x16 acc[2][2];
-    const int P0 = (wy0 + ((i32 >> 1) & 1)) * PW + wx0 + 2 * (i32 >> 2) + (i32 & 1);
-    int b_hi[3];
-#pragma unroll
-    for (int kx = 0; kx < 3; ++kx) b_hi[kx] = (P0 + kx) * 4 + ((2 * h) ^ (((P0 + kx) >> 2) & 3));
-    const int a_hi = i32 * 4 + ((2 * h) ^ ((i32 >> 2) & 3));
-
-    f16x8 fr[2][8];
-    auto read_frag = [&](int set, int buf, int slot, int ky, int kx, int i) {
-        const f16x8* si = reinterpret_cast<const f16x8*>(s_in + buf * IN_SZ) + ky * PW * 4;
-        const f16x8* sw = reinterpret_cast<const f16x8*>(s_w + slot * WS) + kx * 64 * 4;
-        const int bx = b_hi[kx] ^ ((ky & 1) << 1);
-        switch (i) {
-            case 0: fr[set][0] = sw[a_hi]; break;
-            case 1: fr[set][1] = si[bx]; break;
-            case 2: fr[set][2] = si[bx + 2 * PW * 4]; break;
-            case 3: fr[set][3] = sw[a_hi + 32 * 4]; break;
-            case 4: fr[set][4] = si[bx ^ 1]; break;
-            case 5: fr[set][5] = si[(bx ^ 1) + 2 * PW * 4]; break;
-            case 6: fr[set][6] = sw[a_hi ^ 1]; break;
-            default: fr[set][7] = sw[(a_hi ^ 1) + 32 * 4]; break;
-        }
-    };
-
-    int id = blockIdx.x;
-    if (id >= total) return;
-    Tile cur = tile_of(id);
-    // prologue: gray tile -> s_g[0]; conv1a chunk 0 -> halo buffer 0; weight stages 0..2 -> slots 0..2
-    {
-        const __amdgpu_buffer_rsrc_t rs = gray_rsrc(cur);
-#pragma unroll
-        for (int j = 0; j < NGL; ++j) gray_load(rs, cur, j);
-#pragma unroll
-        for (int ky = 0; ky < 3; ++ky)
-#pragma unroll
-            for (int i = 0; i < NWA; ++i) dma_w(0, ky, ky, i);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this thread reads back what its own wave's DMA wrote
-        gray_store(0);
-    }
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();  // gray tile, tap table, bias table
-#pragma unroll
-    for (int pos = 0; pos <= 12; ++pos) p_step(pos, 0, 0, 0, cur);
-    asm volatile("s_waitcnt vmcnt(0)\n\ts_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-#pragma unroll
-    for (int i = 0; i < 8; ++i) read_frag(0, 0, 0, 0, 0, i);
-
-    int sidx = 0, gb = 0;
-    bool e_now = false, e_prev = false;
-    for (;;) {
-        const bool more = id + (int)gridDim.x < total;
-        const Tile nxt = tile_of(more ? id + (int)gridDim.x : id);
-        const __amdgpu_buffer_rsrc_t rs_g = gray_rsrc(nxt);
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int j = 0; j < 2; ++j)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-        auto chunk = [&](auto c_c) {
-            constexpr int C = decltype(c_c)::value, PAR = C & 1;
-            const bool has_next = C < 3 || more;        // the chunk after this one exists
-            const Tile& ntl = C < 3 ? cur : nxt;
-            constexpr int NC = (C + 1) & 3;
-            const int ngb = C < 3 ? gb : gb ^ 1;        // gray buffer the next chunk is produced from
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                // my VMEM instructions up to the stage before last are done (issued since: the previous stage's and, around a tile
-                // boundary, the E output stores), then everyone's
-                if (ky == 0) {
-                    if (C == 1) {   // previous stage (0,2): weight pieces + the gray loads of the next tile
-                        if (more) wait_vm_c<NWA + NGL>(); else wait_vm_c<NWA>();
-                    } else if (e_now) wait_vm_c<NWA + E>();
-                    else wait_vm_c<NWA>();
-                } else if (!has_next) {
-                    wait_vm_c<0>();
-                } else if (ky == 1 && e_prev) {
-                    wait_vm_c<NWA + E>();
-                } else {
-                    wait_vm_c<NWA>();
-                }
-                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                __builtin_amdgcn_s_barrier();
-                e_prev = e_now;
-                e_now = false;
-                const int slot = sidx & 3, slot1 = (sidx + 1) & 3, slot3 = (sidx + 3) & 3;
-#pragma unroll
-                for (int kx = 0; kx < 3; ++kx) {
-                    const int T = 3 * ky + kx, S = (T + PAR) & 1;
-                    int fslot = 0;
-                    // fillers of tap kx: slots 0-7 the fragment reads of the next tap; slots 2, 5, 8, 11 a conv1a step of the next chunk
-                    // (first two stages; every step requests the LDS operands of the next one, so they are three MFMAs old when used); slots 9, 10 the VMEM work: weight pieces of the stage three ahead (class A: taps 0, 0, 1)
-                    // and, in the third stage of chunk 0, the six gray-tile loads; the gray store in the third stage of chunk 1
-                    auto filler = [&]() {
-                        const int f = fslot++;
-                        if (f < 8) {
-                            if (T < 8) read_frag(1 - S, PAR, kx == 2 ? slot1 : slot, (T + 1) / 3, (T + 1) % 3, f);
-                            else read_frag(1 - S, 1 - PAR, slot1, 0, 0, f);
-                        }
-                        if ((f == 2 || f == 5 || f == 8 || f == 11) && ky < 2) {
-                            const int pos = ky * 12 + kx * 4 + (f - 2) / 3;
-                            if (has_next && pos <= 12) p_step(pos, NC, ngb, 1 - PAR, ntl);
-                        }
-                        if (f == 9 || f == 10) {
-                            const int d = kx * 2 + (f - 9);  // 0..5
-                            if (d < NWA && has_next) dma_w(NC, ky, slot3, d);
-                            if (C == 0 && ky == 2 && more) gray_load(rs_g, nxt, d);
-                            if (C == 1 && ky == 2 && d == 0 && more) gray_store(gb ^ 1);
-                        }
-                        PIN();
-                    };
-                    PIN();
-                    acc[0][0] = mfma16(fr[S][0], fr[S][1], acc[0][0]); filler();
-                    acc[0][1] = mfma16(fr[S][0], fr[S][2], acc[0][1]); filler();
-                    acc[1][0] = mfma16(fr[S][3], fr[S][1], acc[1][0]); filler();
-                    acc[1][1] = mfma16(fr[S][3], fr[S][2], acc[1][1]); filler();
-                    acc[0][0] = mfma16(fr[S][0], fr[S][4], acc[0][0]); filler();
-                    acc[0][1] = mfma16(fr[S][0], fr[S][5], acc[0][1]); filler();
-                    acc[1][0] = mfma16(fr[S][3], fr[S][4], acc[1][0]); filler();
-                    acc[1][1] = mfma16(fr[S][3], fr[S][5], acc[1][1]); filler();
-                    acc[0][0] = mfma16(fr[S][6], fr[S][1], acc[0][0]); filler();
-                    acc[0][1] = mfma16(fr[S][6], fr[S][2], acc[0][1]); filler();
-                    acc[1][0] = mfma16(fr[S][7], fr[S][1], acc[1][0]); filler();
-                    acc[1][1] = mfma16(fr[S][7], fr[S][2], acc[1][1]); filler();
-                }
-                ++sidx;
-            }
-        };
-        chunk(std::integral_constant<int, 0>{});
-        chunk(std::integral_constant<int, 1>{});
-        chunk(std::integral_constant<int, 2>{});
-        chunk(std::integral_constant<int, 3>{});
-        {
-            const int ln = fresh_lane(), hh = ln >> 5;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(s_bias + mt * 32 + 8 * j + 4 * hh);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        acc[mt][nt][4 * j] += bv[0]; acc[mt][nt][4 * j + 1] += bv[1];
-                        acc[mt][nt][4 * j + 2] += bv[2]; acc[mt][nt][4 * j + 3] += bv[3];
-                    }
-                }
-            const int img_bytes = (p.H >> 1) * (p.W >> 1) * p.Cout * 4;
-            BufStore st{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)cur.b * img_bytes, 0, img_bytes, 0x00020000)};
-            epilogue_sh8_st<true>(acc, st, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, 0, ln);
-            e_now = true;
-        }
-        if (!more) break;
-        cur = nxt;
-        gb ^= 1;
-        id += gridDim.x;
-    }
-#endif
 }
 
 // conv1a + conv1b + pool on the stage machinery of conv3x3_dma_kernel.  Differences to the register-staged kernel above:
@@ -1612,6 +1273,7 @@ __global__ __launch_bounds__(512, 2) void conv1ab_mfma_kernel(const ConvF16Args 
         chunk(std::integral_constant<int, 3>{});
         {
             const int ln = fresh_lane(), hh = ln >> 5;
+            mfma_results_guard();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1619,8 +1281,8 @@ __global__ __launch_bounds__(512, 2) void conv1ab_mfma_kernel(const ConvF16Args 
                     const f32x4 bv = *reinterpret_cast<const f32x4*>(s_bias + mt * 32 + 8 * j + 4 * hh);
 #pragma unroll
                     for (int nt = 0; nt < 2; ++nt) {
-                        acc[mt][nt][4 * j] += bv[0]; acc[mt][nt][4 * j + 1] += bv[1];
-                        acc[mt][nt][4 * j + 2] += bv[2]; acc[mt][nt][4 * j + 3] += bv[3];
+                        acc[mt][nt][4 * j] = fma_winv(acc[mt][nt][4 * j], p.winv, bv[0]); acc[mt][nt][4 * j + 1] = fma_winv(acc[mt][nt][4 * j + 1], p.winv, bv[1]);
+                        acc[mt][nt][4 * j + 2] = fma_winv(acc[mt][nt][4 * j + 2], p.winv, bv[2]); acc[mt][nt][4 * j + 3] = fma_winv(acc[mt][nt][4 * j + 3], p.winv, bv[3]);
                     }
                 }
             const int img_bytes = (p.H >> 1) * (p.W >> 1) * p.Cout * 4;
@@ -1753,12 +1415,10 @@ void launch_conv1ab_f16x3(const ConvF16Args& a, const Conv1aArgs& c1, hipStream_
     const long long items = (long long)((a.H + 15) / 16) * ((a.W + 31) / 32) * a.B;  // Cout = 64: one cout slice
     dim3 grid((unsigned)std::min<long long>(items, cu_count()));                     // persistent, one workgroup per CU (135 KB of LDS)
     const long long out_img_bytes = (long long)(a.H / 2) * (a.W / 2) * a.Cout * 4;
-    // a.staged (debug requests "sp.conv_staged" / "sp.conv1ab_staged"): 1 = the register-staged kernel (conv1a in fp32 on the VALU),
-    // 2 = round 2's LDS-DMA kernel with conv1a as VALU fillers (A/B timing of the round-3 change)
+    // a.staged (debug requests "sp.conv_staged" / "sp.conv1ab_staged"): the register-staged kernel (conv1a in fp32 on the VALU)
     if (a.staged != 1 && !a.post_scale && !c1.post_scale && a.Cout == 64 && a.H % 2 == 0 && a.W % 2 == 0 && out_img_bytes < (1ll << 31) &&
         (long long)c1.C * c1.H * c1.W * 4 < (1ll << 31)) {
-        if (a.staged == 2) hipLaunchKernelGGL(conv1ab_dma_kernel, grid, dim3(CT), 0, s, a, c1);
-        else hipLaunchKernelGGL(conv1ab_mfma_kernel, grid, dim3(CT), 0, s, a, c1);
+        hipLaunchKernelGGL(conv1ab_mfma_kernel, grid, dim3(CT), 0, s, a, c1);
         return;
     }
     if (a.post_scale) hipLaunchKernelGGL(conv1ab_f16x3_kernel<true>, grid, dim3(CT), 0, s, a, c1);

@@ -47,7 +47,7 @@ __device__ __attribute__((noinline)) void epilogue_ragged(const GemmF16Args& p, 
     for (int j = 0; j < 16; ++j) {
         const int f = fb + j;
         if (f >= p.N) break;
-        float x = w[j];
+        float x = w[j] * p.winv;
         if (p.bias) x += p.bias[f];
         if (p.relu) x = fmaxf(x, 0.f);
         if (p.post_scale) x = __fadd_rn(__fmul_rn(x, p.post_scale[f]), p.post_shift[f]);
@@ -240,8 +240,9 @@ __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16
                     const float* bp = s_par + (fb - n0);
 #pragma unroll
                     for (int j = 0; j < 16; j += 4) {
-                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + j);
-                        w[j] += bv.x; w[j + 1] += bv.y; w[j + 2] += bv.z; w[j + 3] += bv.w;
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + j);  // acc x winv (power of two: exact) + bias, one rounding
+                        w[j] = fma_winv(w[j], p.winv, bv.x); w[j + 1] = fma_winv(w[j + 1], p.winv, bv.y);
+                        w[j + 2] = fma_winv(w[j + 2], p.winv, bv.z); w[j + 3] = fma_winv(w[j + 3], p.winv, bv.w);
                     }
                 }
                 if (fbase < p.rotary_cols) {  // lightglue.py:36-43, pairs (2i, 2i+1); 8 frequencies per lane

@@ -104,6 +104,7 @@ __global__ __launch_bounds__(HT, 2) void heads_f16x3_kernel(const HeadsF16Args p
         }
         // epilogue: + bias (and the open variant's BatchNorm affine), soft-max over features 0..64, depth-to-space
         float m = -__builtin_inff();
+        mfma_results_guard();
 #pragma unroll
         for (int ft = 0; ft < 3; ++ft)
 #pragma unroll
@@ -114,7 +115,7 @@ __global__ __launch_bounds__(HT, 2) void heads_f16x3_kernel(const HeadsF16Args p
                 const f32x4 tv = *reinterpret_cast<const f32x4*>(s_par + 2 * HF + f0);
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
-                    float v = acc[ft][4 * g + e] + bv[e];
+                    float v = fma_winv(acc[ft][4 * g + e], p.winv, bv[e]);
                     v = __fadd_rn(__fmul_rn(v, sv[e]), tv[e]);
                     if (f0 + e > 64) v = -__builtin_inff();  // padding features
                     acc[ft][4 * g + e] = v;

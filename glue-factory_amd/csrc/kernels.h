@@ -65,7 +65,8 @@ void launch_conv1a(const Conv1aArgs& a, hipStream_t s);
 // ---- conv_f16.hip : same convolutions on the f16 MFMA with split-fp16 (SH8) operands -------------
 struct ConvF16Args {
     const void* in = nullptr;    // SH8 NHWC (B,H,W,Cin)
-    const void* Wt = nullptr;    // SH8 tiled [Cin/16][9][CoutPad][64 B]
+    const void* Wt = nullptr;    // SH8 tiled [Cin/16][9][CoutPad][64 B], values scaled by 1/winv (a power of two, api.hip: pow2_scale)
+    float winv = 1.f;            // accumulators x winv (+ bias) in the epilogue
     int CoutPad = 0;
     const float* bias = nullptr;
     const float* post_scale = nullptr;
@@ -75,7 +76,7 @@ struct ConvF16Args {
     int pool = 0;
     int relu = 1;
     int out_f32 = 0;
-    int staged = 0;              // debug requests only: 1 = register-staged kernels, 2 (conv1ab) = round 2's VALU-conv1a kernel
+    int staged = 0;              // debug requests only: 1 = the register-staged kernels
 };
 void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s);
 void launch_conv1a_sh8(const Conv1aArgs& a, hipStream_t s);
@@ -89,7 +90,8 @@ struct GemmF16Args {
     const void* A1 = nullptr;
     int lda1 = 0;
     int ksplit = 0;
-    const void* W = nullptr;    // SH8 tiled [K/16][Npad][64 B] (w_rowmajor = 0) or SH8 rows [N][ldw]
+    const void* W = nullptr;    // SH8 tiled [K/16][Npad][64 B] (w_rowmajor = 0, values x 1/winv) or SH8 rows [N][ldw]
+    float winv = 1.f;           // accumulators x winv (+ bias) in the epilogue: undoes the power-of-two scaling of uploaded weights
     int Npad = 0;
     int w_rowmajor = 0;
     int ldw = 0;
@@ -120,7 +122,8 @@ void launch_from_sh8(const void* in, float* out, long long elems, hipStream_t s)
 struct FfnF16Args {
     const void* A0 = nullptr;    // SH8 (T,256): the residual stream (k 0..255 of ffn.0)
     const void* A1 = nullptr;    // SH8 (T,256): attention context (k 256..511; the out-projection is folded into W0)
-    const void* W0 = nullptr;    // SH8 tiled [512/16][512][64 B]
+    const void* W0 = nullptr;    // SH8 tiled [512/16][512][64 B], values x 1/winv0
+    float winv0 = 1.f, winv3 = 1.f;  // accumulators x winv (+ bias): the power-of-two scaling of the uploaded weights
     const float* b0 = nullptr;   // (512)
     const float* gamma = nullptr;  // LayerNorm affine (512), act == 0 only
     const float* beta = nullptr;
@@ -138,7 +141,8 @@ void launch_ffn_f16x3(const FfnF16Args& a, hipStream_t s);
 // ---- heads_f16.hip : convPb + soft-max + depth-to-space in one kernel (f16x3 mode) ---------------------------------------
 struct HeadsF16Args {
     const void* in = nullptr;    // SH8 (cells, 256): convPa output
-    const void* W = nullptr;     // SH8 tiled [256/16][Npad][64 B], rows 0..64 real
+    const void* W = nullptr;     // SH8 tiled [256/16][Npad][64 B], rows 0..64 real, values x 1/winv
+    float winv = 1.f;
     int Npad = 0;
     const float* bias = nullptr;        // (>= 65)
     const float* post_scale = nullptr;  // optional BatchNorm affine of the open variant (>= 65)

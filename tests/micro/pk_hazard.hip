@@ -8,7 +8,8 @@
 //   form 2  op_sel      v_pk_fma_f32 r, pg, w, c op_sel:[1,0,0]         (pg = {junk, g}: low lane reads the HIGH half of src0)
 //   form 3  src1 form   v_pk_fma_f32 r, w, gp, c op_sel_hi:[1,0,1]      (the form hipcc emitted in conv1ab: broadcast on src1)
 // in three surroundings: (a) no MFMA anywhere in the kernel, (b) the wave's own independent MFMAs issued right before and after each
-// packed instruction, (c) this wave runs no MFMA but its SIMD partner waves do.  Counts of wrong LOW and wrong HIGH halves per
+// packed instruction, (c) this wave runs no MFMA but its SIMD partner wave does (a workgroup's waves go to the SIMDs cyclically, so waves w
+// and w + 4 of a 512-thread workgroup share a SIMD: waves 4-7 run the MFMAs, waves 0-3 the packed FMAs).  Counts of wrong LOW and wrong HIGH halves per
 // (surrounding, form) are printed; all registers of the packed instruction are disjoint from the MFMA operands and accumulators.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -28,7 +29,7 @@ __device__ __forceinline__ float rnd(unsigned& s) {
     else if (form == 2) asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0]" : "=v"(R) : "v"(G), "v"(W), "v"(C));   \
     else asm volatile("v_pk_fma_f32 %0, %2, %1, %3 op_sel_hi:[1,0,1]" : "=v"(R) : "v"(G), "v"(W), "v"(C));
 
-// surround: 0 = no MFMA, 1 = own MFMAs around every packed instruction, 2 = only the odd waves run MFMAs, the even waves run the packed FMAs
+// surround: 0 = no MFMA, 1 = own MFMAs around every packed instruction, 2 = waves 4-7 run only MFMAs, their SIMD partners 0-3 only the packed FMAs
 template <int SURROUND, int FORM>
 __global__ __launch_bounds__(512) void pk_probe(unsigned* bad, float* sink, int iters) {
     unsigned s = (blockIdx.x * 512u + threadIdx.x) * 2654435761u + 977u * FORM + 131u * SURROUND;
@@ -36,8 +37,8 @@ __global__ __launch_bounds__(512) void pk_probe(unsigned* bad, float* sink, int 
     for (int j = 0; j < 8; ++j) { a[j] = (_Float16)rnd(s); b[j] = (_Float16)rnd(s); }
     f32x16 acc0 = {0}, acc1 = {0}, acc2 = {0}, acc3 = {0};
     const int wave = threadIdx.x >> 6;
-    const bool do_mfma = SURROUND == 1 || (SURROUND == 2 && (wave & 1));
-    const bool do_pk = SURROUND != 2 || !(wave & 1);
+    const bool do_mfma = SURROUND == 1 || (SURROUND == 2 && (wave & 4));
+    const bool do_pk = SURROUND != 2 || !(wave & 4);
     unsigned bad_lo = 0, bad_hi = 0;
     for (int i = 0; i < iters; ++i) {
         const float g = rnd(s), w0 = rnd(s), w1 = rnd(s), c0 = rnd(s), c1 = rnd(s), junk = rnd(s) * 1024.0f;
