@@ -78,12 +78,15 @@ __device__ __forceinline__ void mma3x2(const f16x8 ah, const f16x8 al, const f16
     c0 = mfma16(al, bh0, c0);
     c1 = mfma16(al, bh1, c1);
 }
-// acc * winv + bias with winv a wave-uniform power of two (the scaling of uploaded weights, api.hip: pow2_scale): ONE scalar-operand
-// v_fma_f32, written as asm so that no translation unit turns runs of them into v_pk_fma_f32 with an op_sel broadcast of the scalar
-// (build.py / pk_scan.py keep those out of kernels with MFMAs).  hipcc's hazard recognizer does not look inside asm statements: an
-// accumulator an MFMA has just written must not be read by this instruction before the MFMA has retired -- every epilogue that
-// starts with it executes mfma_results_guard() first (both are volatile, so they keep their order).
-__device__ __forceinline__ float fma_winv(float acc, float winv, float bias) {
+// acc * winv + bias with winv a wave-uniform power of two (the scaling of uploaded weights, api.hip: pow2_scale): the product is
+// exact, so the fma rounds once, exactly like "accumulate unscaled, then add the bias".
+__device__ __forceinline__ float fma_winv(float acc, float winv, float bias) { return __builtin_fmaf(acc, winv, bias); }
+// The same as ONE scalar-operand v_fma_f32 written in asm, for the translation unit that keeps hipcc's packed-fp32 code generation
+// (ffn_f16.hip): there a run of plain fmas becomes v_pk_fma_f32 with an op_sel broadcast of the scalar, which build.py / pk_scan.py
+// keep out of barrier intervals that hold MFMAs.  hipcc's hazard recognizer does not look inside asm statements, and MFMA builtins
+// are free to move across an asm statement they share no operand with: use it only where scheduling fences (sched_barrier after the
+// last MFMA) and mfma_results_guard() -- both volatile, so they keep their order -- separate it from the MFMAs that wrote `acc`.
+__device__ __forceinline__ float fma_winv_asm(float acc, float winv, float bias) {
     float r;
     asm volatile("v_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(acc), "s"(winv), "v"(bias));
     return r;

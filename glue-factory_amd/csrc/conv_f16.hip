@@ -164,7 +164,6 @@ template <bool GENERIC>
 __device__ __forceinline__ void conv_epilogue(const ConvF16Args& p, f32x16 (&acc)[2][2], const float* sb, int b, int yw, int xw, int n0, int lane) {
     const int i32 = lane & 31, h = lane >> 5;
     if (sb) {
-        mfma_results_guard();
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -692,7 +691,6 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
         // epilogue: bias (LDS table of the whole layer), ReLU, pool, SH8 -- E unconditional buffer stores per wave
         {
             const float* sb = s_bias + cur.n0;
-            mfma_results_guard();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
@@ -1273,7 +1271,6 @@ __global__ __launch_bounds__(512, 2) void conv1ab_mfma_kernel(const ConvF16Args 
         chunk(std::integral_constant<int, 3>{});
         {
             const int ln = fresh_lane(), hh = ln >> 5;
-            mfma_results_guard();
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll

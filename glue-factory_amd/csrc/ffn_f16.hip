@@ -254,8 +254,8 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(b0 + ft * 32 + 8 * g);
 #pragma unroll
                 for (int tt = 0; tt < 4; ++tt) {
-                    acc[ft][tt][4 * g] = fma_winv(acc[ft][tt][4 * g], p.winv0, bv.x); acc[ft][tt][4 * g + 1] = fma_winv(acc[ft][tt][4 * g + 1], p.winv0, bv.y);
-                    acc[ft][tt][4 * g + 2] = fma_winv(acc[ft][tt][4 * g + 2], p.winv0, bv.z); acc[ft][tt][4 * g + 3] = fma_winv(acc[ft][tt][4 * g + 3], p.winv0, bv.w);
+                    acc[ft][tt][4 * g] = fma_winv_asm(acc[ft][tt][4 * g], p.winv0, bv.x); acc[ft][tt][4 * g + 1] = fma_winv_asm(acc[ft][tt][4 * g + 1], p.winv0, bv.y);
+                    acc[ft][tt][4 * g + 2] = fma_winv_asm(acc[ft][tt][4 * g + 2], p.winv0, bv.z); acc[ft][tt][4 * g + 3] = fma_winv_asm(acc[ft][tt][4 * g + 3], p.winv0, bv.w);
                 }
             }
     }
@@ -467,8 +467,8 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
 #pragma unroll
             for (int j = 0; j < 16; j += 4) {
                 const f32x4 bv = *reinterpret_cast<const f32x4*>(bp + j);
-                w[j] = fma_winv(w[j], p.winv3, bv.x) + resid[ft][tt][j]; w[j + 1] = fma_winv(w[j + 1], p.winv3, bv.y) + resid[ft][tt][j + 1];
-                w[j + 2] = fma_winv(w[j + 2], p.winv3, bv.z) + resid[ft][tt][j + 2]; w[j + 3] = fma_winv(w[j + 3], p.winv3, bv.w) + resid[ft][tt][j + 3];
+                w[j] = fma_winv_asm(w[j], p.winv3, bv.x) + resid[ft][tt][j]; w[j + 1] = fma_winv_asm(w[j + 1], p.winv3, bv.y) + resid[ft][tt][j + 1];
+                w[j + 2] = fma_winv_asm(w[j + 2], p.winv3, bv.z) + resid[ft][tt][j + 2]; w[j + 3] = fma_winv_asm(w[j + 3], p.winv3, bv.w) + resid[ft][tt][j + 3];
             }
             const int ql = i32 & 3;
             const int tq = m0 + wt3 * 64 + tt * 32 + (i32 & ~3);  // first token of this lane's quad

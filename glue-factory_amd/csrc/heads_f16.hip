@@ -104,7 +104,6 @@ __global__ __launch_bounds__(HT, 2) void heads_f16x3_kernel(const HeadsF16Args p
         }
         // epilogue: + bias (and the open variant's BatchNorm affine), soft-max over features 0..64, depth-to-space
         float m = -__builtin_inff();
-        mfma_results_guard();
 #pragma unroll
         for (int ft = 0; ft < 3; ++ft)
 #pragma unroll
