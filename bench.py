@@ -504,6 +504,12 @@ def main():
                                      "peak": PEAK[args.precision], "unit": "TFLOP/s", "executed_frac": round(a_tf * mult / PEAK[args.precision], 4),
                                      "executed_frac_of_sustained": (round(a_tf * mult / SUSTAINED[args.precision], 4) if SUSTAINED[args.precision] else None),
                                      "ms_per_step": round(a_ms / nb, 4)}
+        if "sg.sinkhorn" in prof:  # configs[3]: the log-domain Sinkhorn against its byte floor (one sweep of the couplings per iteration)
+            it, ms = 50, prof["sg.sinkhorn"][0] / nb
+            floor = float(B) * (K + 1) * (K + 1) * 4 * it
+            res["sinkhorn"] = {"ms_per_step": round(ms, 4), "iterations": it, "floor_bytes_per_step": floor,
+                               "floor_definition": "B x (K+1)^2 x 4 B read once per iteration (superglue.py:173-201: 50 iterations, two half-steps each)",
+                               "achieved_GBps_vs_floor_bytes": round(floor / (ms * 1e-3) / 1e9, 1), "hbm_peak_GBps": 8000.0}
         if f32_mode is not None:
             res["f32_mode"] = f32_mode
         if world == 1 and not args.no_cpu_baseline:

@@ -1150,6 +1150,7 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
             AttnF16Args a;
             a.q = QKV; a.k = QKV; a.v = QKV; a.ld = ld; a.q_col = 0; a.k_col = kcol; a.v_col = vcol;
             a.out = CTX; a.ldo = 256; a.B = B; a.M = Mc; a.N = Nc; a.heads = 4; a.cross = cross;
+            a.waves = h->taps.count("lg.attn_w4") ? 4 : 8;
             launch_attention_f16x3(a, s);
         } else {
             AttnArgs a;
@@ -1741,6 +1742,7 @@ int mg_test_attention(mg_handle h, const float* q, const float* k, const float* 
         AttnF16Args a;
         a.q = QS; a.k = KS; a.v = VS; a.ld = 256; a.q_col = 0; a.k_col = 0; a.v_col = 0;
         a.out = OS; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+        a.waves = h->taps.count("lg.attn_w4") ? 4 : 8;
         launch_attention_f16x3(a, s);
         launch_from_sh8(OS, out, (long long)T * 256, s);
     } else {

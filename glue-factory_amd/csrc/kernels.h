@@ -210,6 +210,7 @@ struct AttnF16Args {
     int B = 0, M = 0, N = 0;
     int heads = 4;
     int cross = 0;
+    int waves = 8;            // waves per workgroup: 8 = one workgroup per CU, 4 = two (attention_f16.hip)
 };
 void launch_attention_f16x3(const AttnF16Args& a, hipStream_t s);
 
