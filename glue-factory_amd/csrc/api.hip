@@ -998,6 +998,7 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
         if (f16) {
             GemmF16Args g = lin_args_f16(h->convDb, cD, 256, (int)n8);
             g.C = dd; g.ldc = 256;
+            g.l2norm = h->convDb.ps ? 0 : 1;  // descriptor head + F.normalize in one epilogue (the open variant's BatchNorm affine comes first: separate pass)
             launch_gemm_f16x3(g, s);
         } else {
             GemmArgs g = lin_args(h->convDb, cD, 256, (int)n8, dd, 256);
@@ -1007,7 +1008,8 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
     // the dense map is L2-normalised in place only when somebody wants it; otherwise the sampler normalises the four
     // cells it reads (same arithmetic) and the 2 x 315 MB sweep over the map disappears
     const bool want_dense = dense_desc || h->taps.count("sp.dense");
-    if (want_dense) {
+    const bool dense_normalised = f16 && !h->convDb.ps;  // fused into convDb's epilogue (gemm_f16.hip: l2norm)
+    if (want_dense && !dense_normalised) {
         ProfScope ps(h, s, "sp.l2norm");
         launch_l2norm_rows(dd, (long long)n8, 256, s);
     }
@@ -1016,7 +1018,7 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
         ProfScope ps(h, s, "sp.sample");
         SampleArgs a;
         a.keypoints = keypoints; a.dense = dd; a.B = B; a.K = conf->max_num_keypoints; a.hc = hc; a.wc = wc;
-        a.mode = conf->sampling; a.desc = descriptors; a.normalize_cells = want_dense ? 0 : 1;
+        a.mode = conf->sampling; a.desc = descriptors; a.normalize_cells = (want_dense || dense_normalised) ? 0 : 1;
         launch_sample(a, s);
     }
     if (heatmap) HIPCHK(hipMemcpyAsync(heatmap, heat, n8 * 64 * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -1150,7 +1152,6 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
             AttnF16Args a;
             a.q = QKV; a.k = QKV; a.v = QKV; a.ld = ld; a.q_col = 0; a.k_col = kcol; a.v_col = vcol;
             a.out = CTX; a.ldo = 256; a.B = B; a.M = Mc; a.N = Nc; a.heads = 4; a.cross = cross;
-            a.waves = h->taps.count("lg.attn_w4") ? 4 : 8;
             launch_attention_f16x3(a, s);
         } else {
             AttnArgs a;
@@ -1404,25 +1405,24 @@ struct GnnRun {
             linear(Lr.mlp3, T, HID, 512, nullptr, 0, XS, 256, o);
         }
     }
-    // out[b] = MD0[b, :rowsA] . MD1[b, :rowsW]^T / 16   (MD = projected tokens, "act" storage, image-0 rows then image-1 rows)
+    // The final projection and the similarity behind the assignment, in both arithmetic modes on the fp32 MFMA with float64 stage
+    // sums (gemm.hip PRECISE, as LightGlue's): the Sinkhorn iterations / double soft-max amplify every error of the costs.
+    // MD = fp32 projected tokens (image-0 rows, then image-1 rows), computed from the fp32 descriptor stream X.
+    void final_linear(const LinLayer& L, size_t rows, float* MD) const {
+        GemmArgs g = lin_args(L, X, 256, (int)rows, MD, 256);
+        g.precise = 1;
+        launch_gemm(g, s);
+    }
+    // out[b] = MD0[b, :rowsA] . MD1[b, :rowsW]^T / 16
     void similarity(const float* MD, size_t rowsA, size_t rowsW, float* out) const {
-        if (f16) {
-            GemmF16Args g;
-            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
-            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = out; g.ldc = (int)rowsW; g.M = (int)rowsA; g.N = (int)rowsW; g.K = 256;
-            g.scale = 0.0625f; g.scale_cols = (int)rowsW;
-            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)rowsA * rowsW;
-            launch_gemm_f16x3(g, s);
-        } else {
-            GemmArgs g;
-            g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
-            g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
-            g.C = out; g.ldc = (int)rowsW; g.M = (int)rowsA; g.N = (int)rowsW; g.K = 256;
-            g.scale = 0.0625f; g.scale_cols = (int)rowsW;
-            g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)rowsA * rowsW;
-            launch_gemm(g, s);
-        }
+        GemmArgs g;
+        g.A0 = MD; g.lda0 = 256; g.ksplit = 256;
+        g.W = MD + T0 * 256; g.w_rowmajor = 1; g.ldw = 256;
+        g.C = out; g.ldc = (int)rowsW; g.M = (int)rowsA; g.N = (int)rowsW; g.K = 256;
+        g.scale = 0.0625f; g.scale_cols = (int)rowsW;
+        g.batch = B; g.strideA = (long long)M * 256; g.strideW = (long long)N * 256; g.strideC = (long long)rowsA * rowsW;
+        g.precise = 1;
+        launch_gemm(g, s);
     }
 };
 
@@ -1467,7 +1467,7 @@ int mg_sg_forward(mg_handle h, const mg_sg_conf* conf, const float* kpts0, const
     float* MD = QKV;
     {
         ProfScope ps(h, s, "sg.gemm.final_proj");
-        g.linear(h->sg_final, T, g.xa(), 256, nullptr, 0, MD, 256, GnnRun::Opt());
+        g.final_linear(h->sg_final, T, MD);
     }
     {
         ProfScope ps(h, s, "sg.gemm.cost");  // scores / sqrt(256), superglue.py:283-284
@@ -1596,7 +1596,7 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
     float* MD = QKV;
     {
         ProfScope ps(h, s, "gs.match");
-        g.linear(h->gs_final, T, XA, 256, nullptr, 0, MD, 256, Opt());
+        g.final_linear(h->gs_final, T, MD);
         g.similarity(MD, M, N, SIM);
         assign(SIM, h->gs_bin, M, N, log_assignment, matches0, matches1, mscores0, mscores1);
     }
@@ -1605,7 +1605,7 @@ int mg_gs_forward(mg_handle h, const mg_gs_conf* conf, const float* kpts0, const
         float* JS = h->buf("gs.js", (size_t)B * 4 * n0 * n1);
         float* RAW = raw_line_scores ? raw_line_scores : h->buf("gs.raw", (size_t)B * n0 * n1);
         if (!JS || !RAW) return fail(MG_ERR_HIP, "workspace allocation failed");
-        g.linear(h->gs_final_line, T, XA, 256, nullptr, 0, MD, 256, Opt());  // all tokens; only the leading 2*n rows of a pair are used
+        g.final_linear(h->gs_final_line, T, MD);  // all tokens; only the leading 2*n rows of a pair are used
         g.similarity(MD, 2 * (size_t)n0, 2 * (size_t)n1, JS);
         launch_gs_line_scores(JS, reinterpret_cast<const long long*>(junc_idx0), reinterpret_cast<const long long*>(junc_idx1), B, n0, n1, RAW, s);
         assign(RAW, h->gs_line_bin, n0, n1, line_log_assignment, line_matches0, line_matches1, line_mscores0, line_mscores1);
@@ -1742,7 +1742,6 @@ int mg_test_attention(mg_handle h, const float* q, const float* k, const float* 
         AttnF16Args a;
         a.q = QS; a.k = KS; a.v = VS; a.ld = 256; a.q_col = 0; a.k_col = 0; a.v_col = 0;
         a.out = OS; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
-        a.waves = h->taps.count("lg.attn_w4") ? 4 : 8;
         launch_attention_f16x3(a, s);
         launch_from_sh8(OS, out, (long long)T * 256, s);
     } else {

@@ -19,7 +19,7 @@
 
 namespace {
 
-constexpr int KT = 32, QW = 64;  // keys per tile; 64 queries (two MFMA tiles) per wave; NW waves per workgroup (template parameter)
+constexpr int KT = 32, AT = 512, QW = 64;  // keys per tile; 8 waves x 64 queries (two MFMA tiles) per workgroup
 constexpr float RESCALE_THR = 8.f;  // in log2 units
 
 // The probabilities are kept as P' = 2^P_SHIFT * exp2(s - m_run): with the deferred rescale s - m_run <= RESCALE_THR, so
@@ -44,12 +44,7 @@ __device__ __forceinline__ void split_pair(float x0, float x1, unsigned& hi, uns
         : "v"(hi), "v"(x0), "v"(x1));
 }
 
-// NW = 8: one workgroup per CU (two waves per SIMD that run in lockstep behind one barrier per key tile: MFMA phases and soft-max
-// phases of the SIMD partners coincide).  NW = 4: two workgroups per CU, each with its own barrier -- the partners on a SIMD belong to
-// different workgroups and drift apart; the K / V tile is staged twice per CU instead of once (2 pieces per thread).
-template <int NW>
-__global__ __launch_bounds__(64 * NW, 2) void attention_f16x3_kernel(const AttnF16Args p) {
-    constexpr int AT = 64 * NW, NP = 512 / AT;  // threads; staging pieces per thread and operand
+__global__ __launch_bounds__(AT, 2) void attention_f16x3_kernel(const AttnF16Args p) {
     __shared__ u32x4 s_k[2][KT * 16];
     __shared__ u32x4 s_v[2][64 * 8];
 
@@ -63,7 +58,7 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16x3_kernel(const AttnF
     const int Lkv = kside ? p.N : p.M;
     const long long qbase = side ? ((long long)p.B * p.M + (long long)b * p.N) : (long long)b * p.M;
     const long long kbase = kside ? ((long long)p.B * p.M + (long long)b * p.N) : (long long)b * p.M;
-    const int q0 = blockIdx.x * (NW * QW);
+    const int q0 = blockIdx.x * (8 * QW);
     if (q0 >= Lq) return;
 
     const int i32 = lane & 31, h = lane >> 5;
@@ -90,35 +85,27 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16x3_kernel(const AttnF
     float m_run[2] = {-__builtin_inff(), -__builtin_inff()}, l_run[2] = {0.f, 0.f};
 
     const int ntiles = (Lkv + KT - 1) / KT;
-    u32x4 rk[NP], rv[NP];
-    // K: piece (key = tt>>4, c = tt&15).  V: key = tt&31 across lanes (bank spread of the transposing
-    // 2-byte writes), piece c = tt>>5.  tt = t + AT u runs over the 512 pieces of a tile.
+    u32x4 rk, rv;
+    // K: piece (key = t>>4, c = t&15).  V: key = t&31 across lanes (bank spread of the transposing
+    // 2-byte writes), piece c = t>>5.
     auto load_tile = [&](int kt) {
-#pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            const int tt = t + AT * u;
-            const long long row = kbase + min(kt * KT + (tt >> 4), Lkv - 1);
-            rk[u] = Kp[row * ld4 + ((p.k_col + head * 64) >> 2) + (tt & 15)];
-            const long long vrow = kbase + min(kt * KT + (tt & 31), Lkv - 1);
-            rv[u] = Vp[vrow * ld4 + ((p.v_col + head * 64) >> 2) + (tt >> 5)];
-        }
+        const long long row = kbase + min(kt * KT + (t >> 4), Lkv - 1);
+        rk = Kp[row * ld4 + ((p.k_col + head * 64) >> 2) + (t & 15)];
+        const long long vrow = kbase + min(kt * KT + (t & 31), Lkv - 1);
+        rv = Vp[vrow * ld4 + ((p.v_col + head * 64) >> 2) + (t >> 5)];
     };
     auto store_tile = [&](int buf) {
+        const int key = t >> 4, c = t & 15;
+        s_k[buf][key * 16 + (c ^ (key & 15))] = rk;
+        const int vkey = t & 31, vc = t >> 5, g = vc >> 1, part = vc & 1;
+        // key = 16s + 8a + 4hh + e  ->  position 16s + 8hh + 4a + e inside the tile row
+        const int pos = (vkey & 16) | ((vkey & 4) << 1) | ((vkey & 8) >> 1) | (vkey & 3);
+        _Float16* vt = reinterpret_cast<_Float16*>(s_v[buf]);
+        const f16x8 hv = __builtin_bit_cast(f16x8, rv);
 #pragma unroll
-        for (int u = 0; u < NP; ++u) {
-            const int tt = t + AT * u;
-            const int key = tt >> 4, c = tt & 15;
-            s_k[buf][key * 16 + (c ^ (key & 15))] = rk[u];
-            const int vkey = tt & 31, vc = tt >> 5, g = vc >> 1, part = vc & 1;
-            // key = 16s + 8a + 4hh + e  ->  position 16s + 8hh + 4a + e inside the tile row
-            const int pos = (vkey & 16) | ((vkey & 4) << 1) | ((vkey & 8) >> 1) | (vkey & 3);
-            _Float16* vt = reinterpret_cast<_Float16*>(s_v[buf]);
-            const f16x8 hv = __builtin_bit_cast(f16x8, rv[u]);
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int d = 8 * g + j;
-                vt[(d * 8 + ((part * 4 + (pos >> 3)) ^ ((d >> 1) & 7))) * 8 + (pos & 7)] = hv[j];
-            }
+        for (int j = 0; j < 8; ++j) {
+            const int d = 8 * g + j;
+            vt[(d * 8 + ((part * 4 + (pos >> 3)) ^ ((d >> 1) & 7))) * 8 + (pos & 7)] = hv[j];
         }
     };
 
@@ -236,11 +223,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_f16x3_kernel(const AttnF
 
 void launch_attention_f16x3(const AttnF16Args& a, hipStream_t s) {
     const int L = a.M > a.N ? a.M : a.N;
-    if (a.waves == 4) {
-        dim3 grid((L + 4 * QW - 1) / (4 * QW), a.heads, 2 * a.B);
-        hipLaunchKernelGGL(attention_f16x3_kernel<4>, grid, dim3(256), 0, s, a);
-    } else {
-        dim3 grid((L + 8 * QW - 1) / (8 * QW), a.heads, 2 * a.B);
-        hipLaunchKernelGGL(attention_f16x3_kernel<8>, grid, dim3(512), 0, s, a);
-    }
+    dim3 grid((L + 8 * QW - 1) / (8 * QW), a.heads, 2 * a.B);
+    hipLaunchKernelGGL(attention_f16x3_kernel, grid, dim3(AT), 0, s, a);
 }

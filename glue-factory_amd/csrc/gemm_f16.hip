@@ -216,6 +216,40 @@ __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16
     __builtin_amdgcn_s_barrier();                         // s_par visible (also when the k-loop was empty)
     float* C = p.C ? p.C + z * p.strideC : nullptr;
     const int wfu = wu / TOKW;
+    // Fused L2 normalisation of the output rows (SuperPoint's descriptor head: convDb then F.normalize over the 256 channels,
+    // superpoint.py:233-236 -- N == TN, the whole row lives in this workgroup).  Pass 1: bias in place, squared sums per token
+    // (a lane and its partner at lane ^ 32 hold the two halves of a 32-feature tile of the SAME token; the other 128 features sit in
+    // the wave with the other wfu and meet through LDS -- the rings are free after the barrier above).  The store loop below then
+    // scales by 1 / max(||row||, 1e-12) instead of adding the bias.
+    float rnorm[2] = {1.f, 1.f};
+    const bool l2 = p.l2norm != 0;  // launcher: only with N == 256, full tiles, fp32 output, no rotary / ReLU / affine / residual
+    if (l2) {
+        float ss[2] = {0.f, 0.f};
+#pragma unroll
+        for (int ft = 0; ft < 4; ++ft)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float b = s_par[wfu * 128 + ft * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                for (int tt = 0; tt < 2; ++tt) {
+                    const float v = fma_winv(acc[ft][tt][r], p.winv, b);
+                    acc[ft][tt][r] = v;
+                    ss[tt] = __builtin_fmaf(v, v, ss[tt]);
+                }
+            }
+        float* s_red = reinterpret_cast<float*>(s_ring);  // [feature half][token of the tile]
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            ss[tt] += __shfl_xor(ss[tt], 32);
+            if (h == 0) s_red[wfu * TM + wt * 64 + tt * 32 + i32] = ss[tt];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+            const int tl = wt * 64 + tt * 32 + i32;
+            rnorm[tt] = 1.f / fmaxf(sqrtf(s_red[tl] + s_red[TM + tl]), 1e-12f);
+        }
+    }
 #pragma unroll
     for (int ft = 0; ft < 4; ++ft) {
         const int fbase = n0 + wfu * 128 + ft * 32;  // uniform
@@ -236,7 +270,10 @@ __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16
                 w[e] = a0; w[4 + e] = b0; w[8 + e] = a1; w[12 + e] = b1;
             }
             if (full) {
-                {
+                if (l2) {
+#pragma unroll
+                    for (int j = 0; j < 16; ++j) w[j] *= rnorm[tt];
+                } else {
                     const float* bp = s_par + (fb - n0);
 #pragma unroll
                     for (int j = 0; j < 16; j += 4) {

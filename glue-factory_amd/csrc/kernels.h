@@ -92,6 +92,7 @@ struct GemmF16Args {
     int ksplit = 0;
     const void* W = nullptr;    // SH8 tiled [K/16][Npad][64 B] (w_rowmajor = 0, values x 1/winv) or SH8 rows [N][ldw]
     float winv = 1.f;           // accumulators x winv (+ bias) in the epilogue: undoes the power-of-two scaling of uploaded weights
+    int l2norm = 0;             // N == 256 only: rows of C are L2-normalised (x / max(||x||, 1e-12)) after the bias -- SuperPoint's convDb
     int Npad = 0;
     int w_rowmajor = 0;
     int ldw = 0;
@@ -210,7 +211,6 @@ struct AttnF16Args {
     int B = 0, M = 0, N = 0;
     int heads = 4;
     int cross = 0;
-    int waves = 8;            // waves per workgroup: 8 = one workgroup per CU, 4 = two (attention_f16.hip)
 };
 void launch_attention_f16x3(const AttnF16Args& a, hipStream_t s);
 

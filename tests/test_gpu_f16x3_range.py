@@ -26,16 +26,13 @@ def dev():
     return torch.device("cuda:0")
 
 
-@pytest.fixture(scope="module", params=["f32", "f16x3", "f16x3-w4"])
+@pytest.fixture(scope="module", params=["f32", "f16x3"])
 def engine(request, dev):
-    """f16x3-w4: the attention kernel's 4-wave instantiation (two workgroups per CU; debug request `lg.attn_w4`)."""
     from gluefactory_amd import _native
 
     e = _native.Engine(dev)
-    e.set_precision(request.param.split("-")[0])
-    e.mode = request.param.split("-")[0]
-    if request.param.endswith("-w4"):
-        e.debug_request("lg.attn_w4")
+    e.set_precision(request.param)
+    e.mode = request.param
     return e
 
 
