@@ -18,6 +18,9 @@ SHORT = {
     "conv3x3_f16x3_kernel": "sp.conv3x3",
     "conv3x3_dma_kernel": "sp.conv3x3",
     "conv1ab_dma_kernel": "sp.conv1ab",
+    "conv1ab_mfma_kernel": "sp.conv1ab",
+    "gemm_kernel<true, true>": "lg.gemm.sim (precise)",
+    "gemm_kernel<false, true>": "lg.gemm.final_proj (precise)",
     "gemm_f16x3_kernel<false": "gemm (tiled weights)",
     "gemm_f16x3_kernel<true": "lg.gemm.sim",
     "attention_f16x3_kernel": "lg.attn",
