@@ -124,9 +124,10 @@ def cpu_model():
 
 
 def usable_cores():
-    """(threads to use, cores visible): the affinity mask, cut to the cgroup CPU quota when one is set; without a quota a
-    1-GPU box still only owns a 16-core share of its host, and more threads than that oversubscribe it (the oracle ran
-    several times slower that way), so the count is capped there."""
+    """(threads to use, cores visible, where the number comes from): the affinity mask, cut to the cgroup CPU quota when one is
+    set (the GPU boxes of this pool: `cpu.max` = "1600000 100000" = 16 CPUs of a 256-thread host -- more threads than that only
+    time-slice each other: one batch-8 pass took 177 s on 256 threads against 4.8 s on 16); without a quota the count is capped at
+    MG_CPU_CORES (default 16) and cpu_baseline() times an all-visible-cores leg as well."""
     seen = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     n = seen
     for path, parse in (("/sys/fs/cgroup/cpu.max", lambda t: (t.split()[0], t.split()[1])),
@@ -134,10 +135,10 @@ def usable_cores():
         try:
             quota, period = parse(open(path).read())
             if quota not in ("max", "-1"):
-                return max(1, min(n, int(int(quota) / int(period)))), seen
+                return max(1, min(n, int(int(quota) / int(period)))), seen, f"cgroup CPU quota ({path}: {quota} / {period})"
         except (OSError, ValueError, IndexError):
             continue
-    return min(n, int(os.environ.get("MG_CPU_CORES", "16"))), seen
+    return min(n, int(os.environ.get("MG_CPU_CORES", "16"))), seen, "no cgroup quota: default share (MG_CPU_CORES)"
 
 
 def cores_evidence():
@@ -155,13 +156,14 @@ def cores_evidence():
 def cpu_baseline(matcher="lightglue", images="boat", budget_s=60.0, note=lambda m: None, only=None):
     """The CPU oracle (oracle/sp_lg_oracle.py, a restatement of the reference) on a bounded sample of the same workload,
     SURVEY 8(d) protocol: B = 1 and B = 8, 3 warm-up + >= 10 timed repetitions each, time.perf_counter, median, on the threads
-    `usable_cores()` gives (the cgroup quota, else a 16-core share) -- AND a batch-8 leg on ALL visible cores, so that the reported
-    value is the best the host does either way (`value` = the fastest leg, `cores` = its thread count).  A repetition count is cut
+    `usable_cores()` gives: the cgroup CPU quota where one is set (it IS the box's share; stated in `cores_share_source`), else a 16-core
+    share plus a leg on ALL visible cores in a time-limited child process, so that the reported value is the best the host does either
+    way (`value` = the fastest leg, `cores` = its thread count).  A repetition count is cut
     (and said so in `sample`) only if the leg would pass its budget."""
     from oracle import sp_lg_oracle as O
 
     torch.set_grad_enabled(False)
-    cores, cores_seen = usable_cores()
+    cores, cores_seen, cores_source = usable_cores()
     W_sp = O.make_sp_weights(0)
     if matcher == "gluestick":
         return None  # secondary workload: its line inputs are built from the GPU run's keypoints
@@ -205,8 +207,8 @@ def cpu_baseline(matcher="lightglue", images="boat", budget_s=60.0, note=lambda 
     if only is not None:  # child process of the all-cores leg below
         return run(only[1], only[0], budget_s=budget_s)
     legs = [run(1, cores), run(8, cores)]
-    if cores_seen > cores:
-        # every visible core, in a child process with a hard time limit: on a box whose share of the host is smaller than what it sees,
+    if cores_seen > cores and not cores_source.startswith("cgroup"):
+        # no quota tells what this process may use: time every visible core too, in a child process with a hard time limit: on a box whose share of the host is smaller than what it sees,
         # hundreds of threads time-slice each other (first run here: 177 s for one batch-8 pass on 256 threads against 4.8 s on 16)
         import subprocess
 
@@ -224,7 +226,7 @@ def cpu_baseline(matcher="lightglue", images="boat", budget_s=60.0, note=lambda 
         note(f"cpu oracle, all {cores_seen} visible cores: {legs[-1]}")
     best = max(legs, key=lambda l: l["pairs_per_s"])
     return {"value": best["pairs_per_s"], "unit": "pairs/s", "cores": best["threads"], "cores_visible": cores_seen, "cores_share": cores,
-            "cores_evidence": cores_evidence(), "kind": "port", "cpu": cpu_model(),
+            "cores_share_source": cores_source, "cores_evidence": cores_evidence(), "kind": "port", "cpu": cpu_model(),
             "protocol": "median of timed repetitions after warm-up, torch.set_num_threads(threads), time.perf_counter",
             "legs": legs,
             "sample": (f"same workload ({W}x{H}, {K} kpts, {images} images): " +
@@ -513,7 +515,7 @@ def main():
         if f32_mode is not None:
             res["f32_mode"] = f32_mode
         if world == 1 and not args.no_cpu_baseline:
-            note("timing the CPU oracle (B = 1 and B = 8 on the core share, B = 8 on all visible cores; 3 warm-up + up to 10 repetitions each, about 2 min)")
+            note("timing the CPU oracle (B = 1 and B = 8 on the core share, + all visible cores when no cgroup quota defines the share; 3 warm-up + up to 10 repetitions each, 1-2 min)")
             cb = cpu_baseline(matcher=args.matcher, images=args.images, note=note)
             if cb is not None:
                 res["cpu_baseline"] = cb

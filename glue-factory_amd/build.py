@@ -27,6 +27,12 @@ SOURCES = ["api.hip", "gemm.hip", "conv.hip", "conv_f16.hip", "gemm_f16.hip", "a
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 NO_MIX = ["-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
 MIX_ON = {"attention_f16.hip"}
+# conv_f16.hip is built with -fno-honor-nans: under IEEE mode every fmaxf(a, b) is preceded by canonicalising v_max_f32 x, x, x of its
+# inputs and the quad-DPP moves of the 2x2 max-pool stay separate instructions; without NaNs to honour hipcc emits ONE v_max_f32_dpp per
+# pooling step and one v_max per ReLU -- 384 of the ~1200 VALU instructions of a pooled tile epilogue, which no MFMA hides
+# (profiles/r03_i_f16x3_sq_counters.json: 5.0 VALU per MFMA in conv1ab).  The file holds convolutions only: ReLU, max-pool, splits --
+# no infinities, no NaN-producing arithmetic (attention, the assignment and Sinkhorn kernels use -inf masks and keep IEEE semantics).
+NNAN = {"conv_f16.hip"}
 NO_PK = ["-Xclang", "-target-feature", "-Xclang", "-packed-fp32-ops"]
 # One file keeps the feature on: ffn_f16.hip (without it the LayerNorm / GELU phase costs 0.8 ms per step).  What is ENFORCED, on the device
 # assembly of every translation unit after every build (pk_scan.py): no kernel that contains MFMAs may contain a packed-fp32
@@ -57,7 +63,8 @@ def build(force=False, verbose=True):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
         # -save-temps=obj leaves the device assembly of exactly this compilation beside the object (scanned below, then removed)
-        cmd = [hipcc, *FLAGS, *([] if src in MIX_ON else NO_MIX), *([] if src in PK_ON else NO_PK), "-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *([] if src in MIX_ON else NO_MIX), *([] if src in PK_ON else NO_PK), *(["-fno-honor-nans"] if src in NNAN else []),
+               "-save-temps=obj", "-c", os.path.join(CSRC, src), "-o", obj]
         if verbose:
             print(" ".join(cmd), flush=True)
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))

@@ -57,7 +57,7 @@ __device__ __attribute__((noinline)) void epilogue_ragged(const GemmF16Args& p, 
     }
 }
 
-template <bool W_ROWMAJOR, bool RAGGED, int TOKW>
+template <bool W_ROWMAJOR, bool RAGGED, int TOKW, bool L2NORM = false>
 __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16Args p) {
     constexpr int TM = 64 * TOKW, GT = 128 * TOKW;
     constexpr int NWP = 16 / (2 * TOKW), NPW = 2 + NWP;  // weight pieces / all DMA pieces per wave and stage (token pieces: always 2)
@@ -222,8 +222,8 @@ __global__ __launch_bounds__(128 * TOKW, 2) void gemm_f16x3_kernel(const GemmF16
     // the wave with the other wfu and meet through LDS -- the rings are free after the barrier above).  The store loop below then
     // scales by 1 / max(||row||, 1e-12) instead of adding the bias.
     float rnorm[2] = {1.f, 1.f};
-    const bool l2 = p.l2norm != 0;  // launcher: only with N == 256, full tiles, fp32 output, no rotary / ReLU / affine / residual
-    if (l2) {
+    constexpr bool l2 = L2NORM;  // its own instantiation (in the hot ones the extra live values cost qkv 10 %); launcher: N == 256, fp32 output,
+    if (l2) {                    // no rotary / ReLU / affine / residual
         float ss[2] = {0.f, 0.f};
 #pragma unroll
         for (int ft = 0; ft < 4; ++ft)
@@ -412,7 +412,9 @@ void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
     do {                                                                                                            \
         hipLaunchKernelGGL((gemm_f16x3_kernel<RM, RG, 2>), grid, dim3(256), 0, s, a);                                 \
     } while (0)
-    if (a.w_rowmajor) {
+    if (a.l2norm) {
+        hipLaunchKernelGGL((gemm_f16x3_kernel<false, false, 2, true>), grid, dim3(256), 0, s, a);
+    } else if (a.w_rowmajor) {
         if (ragged) MG_GEMM_LAUNCH(true, true);
         else MG_GEMM_LAUNCH(true, false);
     } else {
