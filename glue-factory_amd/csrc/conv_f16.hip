@@ -484,6 +484,57 @@ __device__ __forceinline__ void epilogue_sh8_st(f32x16 (&acc)[2][2], const Store
     }
 }
 
+// Bias + ReLU + 2x2 max-pool + SH8 stores of a POOLED wave tile, starting from the raw accumulators.  x -> relu(x * winv + b) is
+// monotone (winv > 0, and so is the rounding of the fma), hence max over the 2x2 block commutes with it: pooling runs FIRST, on the
+// raw sums, and everything after it on the quarter of the data a lane actually stores -- after the pool the four lanes of a quad hold
+// the same 16 channels of one output pixel and each stores ONE 16-byte piece of them (quad lane ql: hi or lo halves (ql & 1) of channel
+// group ql >> 1), so a lane selects its 8 channels, adds their bias, clamps, and converts only those.  Bit-identical to "bias, ReLU,
+// pool, split everything, pick a piece" (tests/test_gpu_conv_dma.py compares with the register-staged kernels, which still do that).
+// Per (mt, nt) block: 32 v_max_f32_dpp + 8 swaps + 8 selects + 16 + 24 + 4  ~  94 VALU instead of 142.
+template <class Store>
+__device__ __forceinline__ void epilogue_pool_sh8_st(f32x16 (&acc)[2][2], const Store& st, const float* sb, float winv, int H, int W, int Cout, int yw, int xw, int n0,
+                                                     int lane) {
+    const int i32 = lane & 31, h = lane >> 5, ql = i32 & 3, blk = i32 >> 2;
+    const int c4 = Cout >> 2;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const bool upper = (ql & 2) != 0, want_lo = (ql & 1) != 0;
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+        const int ch0 = n0 + mt * 32 + 16 * h;
+        const float* bp = sb + mt * 32 + 16 * h + 8 * (ql >> 1);  // the 8 channels this lane stores
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                float x = acc[mt][nt][r];
+                x = fmaxf(x, dpp_quad_xor1(x));
+                x = fmaxf(x, dpp_quad_xor2(x));
+                v[r] = x;
+            }
+            half_swap8(v);  // 16 consecutive channels of the pooled pixel: v[0..3], v[8..11] = +0..7;  v[4..7], v[12..15] = +8..15
+            // (as opaque register values: a select between ELEMENTS OF v makes hipcc index the array dynamically -- through scratch, whose
+            // loads and stores are VMEM instructions the kernels' counted vmcnt waits do not expect)
+            f32x4 a0 = {v[0], v[1], v[2], v[3]}, a1 = {v[4], v[5], v[6], v[7]}, c0 = {v[8], v[9], v[10], v[11]}, c1 = {v[12], v[13], v[14], v[15]};
+            asm volatile("" : "+v"(a0), "+v"(a1), "+v"(c0), "+v"(c1));
+            const f32x4 ga = upper ? a1 : a0, gc = upper ? c1 : c0;
+            f32x8 g = {ga[0], ga[1], ga[2], ga[3], gc[0], gc[1], gc[2], gc[3]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g[j] = fmaxf(fma_winv(g[j], winv, b0[j]), 0.f);
+                g[4 + j] = fmaxf(fma_winv(g[4 + j], winv, b1[j]), 0.f);
+            }
+            f16x8 hi, lo;
+            split8(g, hi, lo);
+            const u32x4 qh = __builtin_bit_cast(u32x4, hi), qlo = __builtin_bit_cast(u32x4, lo);
+            const u32x4 piece = {want_lo ? qlo[0] : qh[0], want_lo ? qlo[1] : qh[1], want_lo ? qlo[2] : qh[2], want_lo ? qlo[3] : qh[3]};
+            const int oy = (yw >> 1) + nt, ox = (xw >> 1) + blk;
+            st((oy * Wo + ox) * c4 + (ch0 >> 2) + ql, oy < Ho && ox < Wo && ch0 < Cout, piece);
+        }
+    }
+}
+
 #endif
 template <int WY, int WX, bool POOL>
 __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p) {
@@ -691,21 +742,25 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
         // epilogue: bias (LDS table of the whole layer), ReLU, pool, SH8 -- E unconditional buffer stores per wave
         {
             const float* sb = s_bias + cur.n0;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + mt * 32 + 8 * j + 4 * h);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        acc[mt][nt][4 * j] = fma_winv(acc[mt][nt][4 * j], p.winv, bv[0]); acc[mt][nt][4 * j + 1] = fma_winv(acc[mt][nt][4 * j + 1], p.winv, bv[1]);
-                        acc[mt][nt][4 * j + 2] = fma_winv(acc[mt][nt][4 * j + 2], p.winv, bv[2]); acc[mt][nt][4 * j + 3] = fma_winv(acc[mt][nt][4 * j + 3], p.winv, bv[3]);
-                    }
-                }
             const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
             const int img_bytes = Ho * Wo * p.Cout * 4;
             BufStore st{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)cur.b * img_bytes, 0, img_bytes, 0x00020000)};
-            epilogue_sh8_st<POOL>(acc, st, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, cur.n0, lane);
+            if (POOL) {
+                epilogue_pool_sh8_st(acc, st, sb, p.winv, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, cur.n0, lane);
+            } else {
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const f32x4 bv = *reinterpret_cast<const f32x4*>(sb + mt * 32 + 8 * j + 4 * h);
+#pragma unroll
+                        for (int nt = 0; nt < 2; ++nt) {
+                            acc[mt][nt][4 * j] = fma_winv(acc[mt][nt][4 * j], p.winv, bv[0]); acc[mt][nt][4 * j + 1] = fma_winv(acc[mt][nt][4 * j + 1], p.winv, bv[1]);
+                            acc[mt][nt][4 * j + 2] = fma_winv(acc[mt][nt][4 * j + 2], p.winv, bv[2]); acc[mt][nt][4 * j + 3] = fma_winv(acc[mt][nt][4 * j + 3], p.winv, bv[3]);
+                        }
+                    }
+                epilogue_sh8_st<POOL>(acc, st, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, cur.n0, lane);
+            }
             e_now = true;
         }
         if (!more) break;
@@ -1270,21 +1325,10 @@ __global__ __launch_bounds__(512, 2) void conv1ab_mfma_kernel(const ConvF16Args 
         chunk(std::integral_constant<int, 2>{});
         chunk(std::integral_constant<int, 3>{});
         {
-            const int ln = fresh_lane(), hh = ln >> 5;
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 bv = *reinterpret_cast<const f32x4*>(s_bias + mt * 32 + 8 * j + 4 * hh);
-#pragma unroll
-                    for (int nt = 0; nt < 2; ++nt) {
-                        acc[mt][nt][4 * j] = fma_winv(acc[mt][nt][4 * j], p.winv, bv[0]); acc[mt][nt][4 * j + 1] = fma_winv(acc[mt][nt][4 * j + 1], p.winv, bv[1]);
-                        acc[mt][nt][4 * j + 2] = fma_winv(acc[mt][nt][4 * j + 2], p.winv, bv[2]); acc[mt][nt][4 * j + 3] = fma_winv(acc[mt][nt][4 * j + 3], p.winv, bv[3]);
-                    }
-                }
+            const int ln = fresh_lane();
             const int img_bytes = (p.H >> 1) * (p.W >> 1) * p.Cout * 4;
             BufStore st{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)cur.b * img_bytes, 0, img_bytes, 0x00020000)};
-            epilogue_sh8_st<true>(acc, st, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, 0, ln);
+            epilogue_pool_sh8_st(acc, st, s_bias, p.winv, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, 0, ln);
             e_now = true;
         }
         if (!more) break;

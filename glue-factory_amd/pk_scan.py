@@ -11,6 +11,10 @@ tests/micro/diag_conv1ab_det.py, profiles/r03_pk_hazard.md).  The rule enforced 
     waves of the workgroup have retired their MFMAs behind a barrier before the first broadcast issues and no MFMA is issued before
     the next barrier.  The allow-list entry names the barriers that do the separating, so a reader can find them in the source.
 
+A second rule rides along: the kernels named in NO_SCRATCH count their VMEM instructions by hand (one `s_waitcnt vmcnt(N)` per stage
+with a compile-time N: LDS-DMA pieces and output stores are issued unconditionally so that the count is exact).  A register spill is a
+`scratch_*` instruction -- a VMEM operation hipcc adds behind the author's back -- so any scratch access in those kernels fails the build.
+
 build.py runs this after compiling (same flags as the objects) and fails the build on a violation.
 """
 import re
@@ -21,6 +25,7 @@ ALLOW = {
     "ffn_f16x3_kernel": "phase 2 (bias / LayerNorm / GELU / split) runs between the `__syncthreads()` that ends phase 1's stage loop and the "
                         "one that precedes phase 3's first MFMA; one workgroup per CU (158 KB of LDS), so no other workgroup's MFMAs share the SIMD",
 }
+NO_SCRATCH = ("conv3x3_dma_kernel", "conv1ab_mfma_kernel")  # counted vmcnt waits (conv_f16.hip)
 _PK = re.compile(r"\bv_pk_(?:fma|mul|add)_f32\b")
 _MFMA = re.compile(r"\bv_mfma_")
 _FUNC = re.compile(r"^([A-Za-z_][\w$.]*):\s*(?:;.*)?$")
@@ -77,6 +82,9 @@ def scan(asm, src="<asm>"):
                                   f"(not in pk_scan.ALLOW), e.g. `{bc[0]}`")
             elif mixed:
                 violations.append(f"{src}: {name}: {mixed} s_barrier interval(s) hold both an MFMA and a broadcasting packed-fp32 instruction")
+        n_scratch = sum(1 for l in body if l.startswith("scratch_"))
+        if n_scratch and any(k in name for k in NO_SCRATCH):
+            violations.append(f"{src}: {name}: {n_scratch} scratch instructions in a kernel whose vmcnt waits are counted by hand")
         if n_mfma or pk:
             report[name] = {"mfma": n_mfma, "pk_f32": len(pk), "pk_f32_broadcast": len(bc), "barrier_intervals_with_both": mixed}
     return violations, report
