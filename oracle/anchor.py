@@ -120,3 +120,14 @@ def matcher_floats(fwd, p, ref32, data, W, name, keys, conf=None, replay=None, s
                     e[who] = max(e[who], score_rows(own, ms, a64))
         res[s0] = anchored_errs(e["hip"], e["cpu"], f"{name} {s0}/{s1}")
     return res, r64
+
+
+_MEMO = {}
+
+
+def memo(key, make):
+    """Results of the CPU oracle / anchor that several parametrisations of a GPU test share (both arithmetic modes run on the same seeded
+    inputs): computed once per process.  `key` must determine the inputs completely."""
+    if key not in _MEMO:
+        _MEMO[key] = make()
+    return _MEMO[key]

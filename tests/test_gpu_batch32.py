@@ -66,8 +66,9 @@ def run_case(dev, precision, B, H, W, Hv, K, oracle_pairs):
     assert bool((p["keypoint_scores0"] > 0).all()) and bool((p["keypoint_scores1"] > 0).all()), "an image produced fewer than K keypoints"
     for i in oracle_pairs:
         data = {"view0": {"image": im0[i:i + 1], "image_size": size[:1]}, "view1": {"image": im1[i:i + 1], "image_size": size[:1]}}
-        ref = O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
-        anchor = AN.TwoViewAnchor(data, W_sp, W_lg, spc, dict(filter_threshold=0.1))  # the oracle in float64: what 1e-4 is measured against
+        # (oracle and float64 anchor of a pair are shared by the two arithmetic modes: same seeded inputs)
+        ref = AN.memo(("b32.ref", H, W, Hv, K, i), lambda: O.two_view_forward(data, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True))
+        anchor = AN.memo(("b32.anchor", H, W, Hv, K, i), lambda: AN.TwoViewAnchor(data, W_sp, W_lg, spc, dict(filter_threshold=0.1)))  # float64: what 1e-4 is measured against
         r = TA.check_two_view(p, ref, i, K, 0.1, tag=f"{W}x{H} K{K} B{B} {precision}", anchor=anchor)
         # moderate |sim| (final_proj = 3 I): the fp32 CPU path is itself within 1e-4 of fp64, so the bound applied was north_star's 1e-4
         assert all(v["bound"] == 1e-4 for k, v in r["floats"].items() if k != "log_assignment"), r["floats"]

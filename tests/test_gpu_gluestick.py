@@ -86,11 +86,12 @@ def test_gluestick_vs_oracle_large(dev, precision):
     B, M, N, n0, n1 = 2, 1000, 1100, 250, 230
     data = mod.gs_inputs(B, M, N, n0, n1, 7, corresponding=True)  # lines of image 1 are the counterparts of image 0's: matches exist
     W = O.make_gs_weights(4, **O.GS_GOLDEN)
-    ref = O.gluestick_forward(data, W, filter_threshold=0.2)
+    ref = AN.memo(("gslarge.ref",), lambda: O.gluestick_forward(data, W, filter_threshold=0.2))  # shared by the two arithmetic modes
     p = _module(W, 0.2, precision)(_to(data, dev))
     # floats of both runs against the oracle in float64: 1e-4, or 2 x the fp32 CPU path's own error where that exceeds 1e-4 (oracle/anchor.py)
+    r64 = AN.memo(("gslarge.r64",), lambda: O.gluestick_forward(O.cast(data, torch.float64), O.cast(W, torch.float64), filter_threshold=0.2))
     AN.matcher_floats(O.gluestick_forward, p, ref, data, W, f"GS large {precision}", ("log_assignment", "line_log_assignment", "raw_line_scores"),
-                      dict(filter_threshold=0.2), scores=GS_SCORES)
+                      dict(filter_threshold=0.2), scores=GS_SCORES, r64=r64)
     # assignments identical except at proven near-ties of the oracle's own decision (oracle/tie_aware.py); no percentage
     import tie_aware as TA
 

@@ -284,14 +284,15 @@ def test_lightglue_vs_oracle_fullsize(dev, B, M, N, precision):
     k1 = torch.gather(k0, 1, perm[..., None].expand(-1, -1, 2)) * 0.9 + 2.0 * torch.randn(B, N, 2, generator=g)
     d1 = torch.nn.functional.normalize(torch.gather(d0, 1, perm[..., None].expand(-1, -1, 256)) + 0.03 * torch.randn(B, N, 256, generator=g), dim=-1)
     data = {"keypoints0": k0, "keypoints1": k1, "descriptors0": d0, "descriptors1": d1, "view0": {"image_size": size}, "view1": {"image_size": size}}
-    ref = O.lightglue_forward(data, W, filter_threshold=0.1)
+    ref = AN.memo(("lgfull.ref", B, M, N), lambda: O.lightglue_forward(data, W, filter_threshold=0.1))
     m = _lg_module(dev, W, 0.1, precision)
     to = lambda x: {k: (to(v) if isinstance(v, dict) else v.to(dev)) for k, v in x.items()}
     p = m(to(data))
     # stress weights (final_proj = 8 I) push |sim| past 1e2, where the fp32 CPU log_assignment is itself ~1e-3 from the exact value:
     # every float of both runs is measured against the oracle in float64 (oracle/anchor.py: 1e-4, or 2 x the CPU path's own error)
+    r64 = AN.memo(("lgfull.r64", B, M, N), lambda: AN.lightglue64(data, W, filter_threshold=0.1))
     AN.matcher_floats(O.lightglue_forward, p, ref, data, W, f"LG B{B} M{M} N{N} {precision}", ("ref_descriptors0", "ref_descriptors1", "log_assignment"),
-                      dict(filter_threshold=0.1))
+                      dict(filter_threshold=0.1), r64=r64)
     print(f"[{precision}] max|desc err| {(p['ref_descriptors0'][:, 0].cpu() - ref['ref_descriptors0'][:, 0]).abs().max().item():.2e} "
           f"max|log_assignment err| {(p['log_assignment'].cpu() - ref['log_assignment']).abs().max().item():.2e}")
     # assignments: identical, except where the oracle's own row / column / threshold decision is closer than twice the measured
@@ -337,21 +338,24 @@ def test_two_view_boat_golden(dev, golden, variant, precision):
     p = pipe(data)
     assert sorted(p.keys()) == list(g[variant + ".keys"])
     # the oracle reproduces the golden (= the reference run on this pair) bit for bit; its score maps then decide what is a near-tie
-    ref = O.two_view_forward({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in data.items()}, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
-    for k in ("keypoints0", "keypoints1"):
-        assert torch.equal(ref[k], g[f"{variant}.{k}"])
     lgc = dict(filter_threshold=0.1)
     host = lambda d: {k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in d.items()}
-    TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat {variant}/{precision}", anchor=AN.TwoViewAnchor(host(data), W_sp, W_lg, spc, lgc))
+    hd = host(data)
+    ref = AN.memo(("boat.ref", variant), lambda: O.two_view_forward(hd, W_sp, W_lg, spc, lgc, with_maps=True))  # shared by the two arithmetic modes
+    for k in ("keypoints0", "keypoints1"):
+        assert torch.equal(ref[k], g[f"{variant}.{k}"])
+    TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat {variant}/{precision}", anchor=AN.memo(("boat.anchor", variant), lambda: AN.TwoViewAnchor(hd, W_sp, W_lg, spc, lgc)))
     # shifted self-pair: genuine correspondences
     a = im0[:, :, 0:640, 0:800].contiguous()
     b = im0[:, :, 16:656, 24:824].contiguous()
     size = torch.tensor([[800.0, 640.0]], device=dev)
     data = {"view0": {"image": a, "image_size": size}, "view1": {"image": b, "image_size": size}}
     p = pipe(data)
-    ref = O.two_view_forward({k: {kk: vv.cpu() for kk, vv in v.items()} for k, v in data.items()}, W_sp, W_lg, spc, dict(filter_threshold=0.1), with_maps=True)
+    hd = host(data)
+    ref = AN.memo(("boatshift.ref", variant), lambda: O.two_view_forward(hd, W_sp, W_lg, spc, lgc, with_maps=True))
     assert torch.equal(ref["keypoints0"], g[variant + ".shift.keypoints0"]) and torch.equal(ref["matches0"], g[variant + ".shift.matches0"])
-    r = TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat-shift {variant}/{precision}", anchor=AN.TwoViewAnchor(host(data), W_sp, W_lg, spc, lgc))
+    r = TA.check_two_view(cpu(p), ref, 0, 512, 0.1, tag=f"boat-shift {variant}/{precision}",
+                          anchor=AN.memo(("boatshift.anchor", variant), lambda: AN.TwoViewAnchor(hd, W_sp, W_lg, spc, lgc)))
     assert (ref["matches0"] > -1).sum() > 100 and r["m0"]["compared"] > 500
 
 

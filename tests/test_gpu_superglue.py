@@ -95,7 +95,7 @@ def _pairs(B, M, N, seed):
 def test_superglue_vs_oracle_fullsize(dev, B, M, N, precision):
     data = _pairs(B, M, N, B * 11 + M)
     W = O.make_sg_weights(9)
-    ref = O.superglue_forward(data, W, filter_threshold=0.2)
+    ref = AN.memo(("sgfull.ref", B, M, N), lambda: O.superglue_forward(data, W, filter_threshold=0.2))  # shared by the two arithmetic modes
     m = _module(dev, W, 0.2, precision)
     p = m(_to(data, dev))
     cost_err = (p["sinkhorn_cost"].cpu() - ref["sinkhorn_cost"]).abs().max().item()
@@ -105,7 +105,8 @@ def test_superglue_vs_oracle_fullsize(dev, B, M, N, precision):
           f"matches0 agreement {agree:.5f} matched {(ref['matches0'] > -1).float().mean().item():.3f}")
     # floats of both runs against the oracle in float64 (50 Sinkhorn iterations over |cost| ~ 1e2 entries: the fp32 CPU path is itself
     # several 1e-4 from the exact value): 1e-4, or 2 x the CPU path's own error where that exceeds 1e-4 (oracle/anchor.py)
-    AN.matcher_floats(O.superglue_forward, p, ref, data, W, f"SG B{B} M{M} N{N} {precision}", ("sinkhorn_cost", "log_assignment"), dict(filter_threshold=0.2))
+    r64 = AN.memo(("sgfull.r64", B, M, N), lambda: O.superglue_forward(O.cast(data, torch.float64), O.cast(W, torch.float64), filter_threshold=0.2))
+    AN.matcher_floats(O.superglue_forward, p, ref, data, W, f"SG B{B} M{M} N{N} {precision}", ("sinkhorn_cost", "log_assignment"), dict(filter_threshold=0.2), r64=r64)
     # assignments identical except at proven near-ties of the oracle's own decision (oracle/tie_aware.py); no percentage
     import tie_aware as TA
 
@@ -170,7 +171,7 @@ def test_superpoint_superglue_pipeline_2048(dev, precision):
     data = {"view0": {"image": ims[0], "image_size": size}, "view1": {"image": ims[1], "image_size": size}}
     W_sp, W_sg = O.make_sp_weights(0), O.make_sg_weights(9)
     spc, sgc = dict(nms_radius=3, detection_threshold=0.0, max_num_keypoints=K), dict(filter_threshold=0.2)
-    ref = O.two_view_forward(data, W_sp, W_sg, spc, sgc, with_maps=True, matcher=O.superglue_forward)
+    ref = AN.memo(("spsg.ref", H, W, K), lambda: O.two_view_forward(data, W_sp, W_sg, spc, sgc, with_maps=True, matcher=O.superglue_forward))
     assert ref["keypoints0"].shape == (1, K, 2) and ref["log_assignment"].shape == (1, K + 1, K + 1)
     pipe = TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint", "precision": precision, **spc},
                             "matcher": {"name": "gluefactory_nonfree.superglue", "filter_threshold": 0.2, "precision": precision}}).eval()
@@ -179,5 +180,5 @@ def test_superpoint_superglue_pipeline_2048(dev, precision):
     p = {k: v.cpu() for k, v in pipe(_to(data, dev)).items()}
     assert p["matches0"].shape == (1, K) and p["matches0"].dtype == torch.int64
     r = TA.check_two_view(p, ref, 0, K, 0.2, tag=f"SP+SuperGlue {W}x{H} K{K} {precision}",
-                          anchor=AN.TwoViewAnchor(data, W_sp, W_sg, spc, sgc, matcher=O.superglue_forward))
+                          anchor=AN.memo(("spsg.anchor", H, W, K), lambda: AN.TwoViewAnchor(data, W_sp, W_sg, spc, sgc, matcher=O.superglue_forward)))
     assert r["m0"]["compared"] > K // 2 and int((ref["matches0"] > -1).sum()) > 200
