@@ -1,7 +1,7 @@
-# Determinism probe of conv1ab_dma_kernel (conv_f16.hip): identity conv1b weights expose the conv1a channels; see DESIGN.md section 4.
-# runs the DMA kernel twice with identity conv1b weights and compares the two runs with each other (determinism)
+# Determinism probe of the fused conv1a + conv1b kernel (conv_f16.hip; round 2: conv1ab_dma_kernel, where it isolated "hazard 1" of
+# DESIGN.md section 4; round 3: conv1ab_mfma_kernel): identity conv1b weights expose the conv1a channels.
+# Runs the kernel four times with identity conv1b weights and compares the runs with each other (determinism).
 import os, sys, torch
-os.environ.pop("MG_CONV1AB_DMA", None)  # the fused DMA kernel is the default
 sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests"); sys.path.insert(0, "/root/repo/glue-factory_amd")
 import torch.nn.functional as F
 from oracle import sp_lg_oracle as O
