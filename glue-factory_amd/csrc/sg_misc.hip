@@ -140,11 +140,12 @@ __global__ __launch_bounds__(64 * COLS_WAVES) void sinkhorn_cols_kernel(const Si
 // ---- fused iteration (N % 4 == 0, N <= 2048; v stride padded to a multiple of 4) -----------------------------
 // One launch per Sinkhorn iteration reads the couplings ONCE: a workgroup owns 16 consecutive rows (4 waves x 4
 // rows, a row = 8 x 16 bytes per lane held in registers, all 32 loads of a lane in flight together).  Row
-// half-step: u_i from the registers.  Column half-step: with its own fresh u_i every wave reduces its 4 rows to
+// half-step: u_i from the registers.  Column half-step: with its own fresh u_i every wave reduces its RPW rows to
 // one (max, sum) pair per column, the 4 waves combine through LDS and the workgroup writes ONE partial per column;
 // sinkhorn_combine_kernel folds the ceil((M+1)/16) partials of a column into v_j.  Two workgroups share a CU
-// (66 KB LDS, 232 VGPRs each), so one's load phase runs under the other's exponentials.
-constexpr int FW = 4, FR = 4 * FW;  // waves per workgroup, rows per workgroup
+// (66 KB LDS, 232 VGPRs each), so one's load phase runs under the other's exponentials.  Round 3: two rows per wave instead of four
+// (33 KB of LDS, half the registers): four workgroups per CU keep twice as many independent load phases in flight.
+constexpr int FW = 4, RPW = 2, FR = RPW * FW;  // waves per workgroup, rows per wave (round 3: 2, was 4), rows per workgroup
 struct SinkFusedArgs {
     SinkArgs a;
     int nblk;      // row blocks per pair
@@ -162,7 +163,7 @@ __device__ __forceinline__ float fexp(float x) { return __builtin_amdgcn_exp2f(x
 // i.e. plain FMAs.  e and a are <= 1, so nothing overflows; a column whose total falls below 1e-20 (its potential
 // moved by more than ~46 in one iteration: possible in the first iterations on extreme costs) is recomputed exactly,
 // in the log domain, by sinkhorn_combine_kernel.
-__global__ __launch_bounds__(64 * FW, 2) void sinkhorn_fused_kernel(const SinkFusedArgs q) {
+__global__ __launch_bounds__(64 * FW, 8 / RPW) void sinkhorn_fused_kernel(const SinkFusedArgs q) {
     const SinkArgs& p = q.a;
     __shared__ float s_l[FW][2052];
     const int t = threadIdx.x, lane = t & 63, w = t >> 6;
@@ -173,9 +174,9 @@ __global__ __launch_bounds__(64 * FW, 2) void sinkhorn_fused_kernel(const SinkFu
     float* u = p.u + (long long)b * (p.M + 1);
     const float vbin = v[p.N];
 
-    f32x4 z[4][8];
+    f32x4 z[RPW][8];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < RPW; ++k) {
         const int i = blk * FR + w + FW * k;
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
@@ -190,9 +191,9 @@ __global__ __launch_bounds__(64 * FW, 2) void sinkhorn_fused_kernel(const SinkFu
         const int qd = lane + 64 * g;
         vv[g] = qd < nq ? *reinterpret_cast<const f32x4*>(v + 4 * qd) : f32x4{0.f, 0.f, 0.f, 0.f};
     }
-    float ebin[4], ai[4];  // dustbin-column exponential and a_i of this wave's rows
+    float ebin[RPW], ai[RPW];  // dustbin-column exponential and a_i of this wave's rows
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
+    for (int k = 0; k < RPW; ++k) {
         const int i = blk * FR + w + FW * k;
         const bool live = i <= p.M;
         // row half-step: z <- z + v, row max, z <- exp(z - m), row sum
@@ -225,10 +226,15 @@ __global__ __launch_bounds__(64 * FW, 2) void sinkhorn_fused_kernel(const SinkFu
         if (qd >= nq) continue;
         f32x4 cl = z[0][g] * ai[0];
 #pragma unroll
-        for (int k = 1; k < 4; ++k) cl += z[k][g] * ai[k];
+        for (int k = 1; k < RPW; ++k) cl += z[k][g] * ai[k];
         *reinterpret_cast<f32x4*>(&s_l[w][4 * qd]) = cl;
     }
-    if (lane == 0) s_l[w][p.N] = (ebin[0] * ai[0] + ebin[1] * ai[1]) + (ebin[2] * ai[2] + ebin[3] * ai[3]);
+    if (lane == 0) {
+        float eb = ebin[0] * ai[0];
+#pragma unroll
+        for (int k = 1; k < RPW; ++k) eb += ebin[k] * ai[k];
+        s_l[w][p.N] = eb;
+    }
     __syncthreads();
     float* pl = q.pl + ((long long)b * q.nblk + blk) * p.vstride;
     for (int j = t; j <= p.N; j += 64 * FW) {
