@@ -138,8 +138,8 @@ __global__ __launch_bounds__(64 * COLS_WAVES) void sinkhorn_cols_kernel(const Si
 }
 
 // ---- fused iteration (N % 4 == 0, N <= 2048; v stride padded to a multiple of 4) -----------------------------
-// One launch per Sinkhorn iteration reads the couplings ONCE: a workgroup owns 16 consecutive rows (4 waves x 4
-// rows, a row = 8 x 16 bytes per lane held in registers, all 32 loads of a lane in flight together).  Row
+// One launch per Sinkhorn iteration reads the couplings ONCE: a workgroup owns 16 consecutive rows (8 waves x 2
+// rows, a row = 8 x 16 bytes per lane held in registers, all 16 loads of a lane in flight together).  Row
 // half-step: u_i from the registers.  Column half-step: with its own fresh u_i every wave reduces its RPW rows to
 // one (max, sum) pair per column, the 4 waves combine through LDS and the workgroup writes ONE partial per column;
 // sinkhorn_combine_kernel folds the ceil((M+1)/16) partials of a column into v_j.  Two workgroups share a CU
