@@ -956,7 +956,7 @@ int mg_sp_forward(mg_handle h, const mg_sp_conf* conf, const float* image, int B
             a.in = st.in; a.Wt = L.Wh; a.winv = L.winv; a.CoutPad = L.CoutPad; a.bias = L.bias; a.post_scale = L.ps; a.post_shift = L.pt;
             a.out = st.out; a.B = B; a.H = st.Hh; a.W = st.Ww; a.Cin = L.Cin; a.Cout = L.Cout; a.pool = st.pool; a.relu = 1;
             a.out_f32 = 0;
-            a.staged = h->taps.count("sp.conv_staged") ? 1 : 0;
+            a.staged = h->taps.count("sp.conv_staged") ? 1 : h->taps.count("sp.conv_dma32") ? 2 : 0;
             launch_conv3x3_f16x3(a, s);
         } else {
             ConvArgs a;

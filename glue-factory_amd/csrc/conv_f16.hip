@@ -770,6 +770,329 @@ __global__ __launch_bounds__(512, 2) void conv3x3_dma_kernel(const ConvF16Args p
 #endif
 }
 
+// ---- round 3 (end): the same convolution on v_mfma_f32_16x16x32_f16 with TAP PAIRS as the contraction index ------------------
+// tests/micro/mfma_lds_shapes.hip: under this loop's LDS traffic the 16x16x32 shape sustains 13 % more than 32x32x16 (the chip holds a
+// higher clock on it), provided K = 32 is filled without extra instructions.  Here K = 32 = [16 channels of tap T | 16 channels of tap
+// T + 1]: lanes 0-31 of both operands address the first tap of a pair and lanes 32-63 the second (k-group g = lane >> 4: bit 0 = channel
+// half, bit 1 = tap of the pair), which is nothing but a per-lane LDS address.  Nine taps per chunk are odd, so pairs run through the
+// stream of taps of TWO chunks (18 taps = 9 pairs; every layer has an even number of 16-channel chunks): the fifth pair is
+// [tap 8 of chunk c | tap 0 of chunk c + 1].
+//   * a DOUBLE STAGE = two filter rows = 6 taps = 3 pairs x 48 MFMAs per wave, one barrier each (half as many as the kernel above);
+//     3 double stages = 2 chunks.  The data of double stage D + 1 (two weight stages into the other half of the four-slot ring, and the
+//     next halo tile where one falls due) is requested under the first pair of D and awaited (vmcnt 0, or E when output stores were
+//     issued last) before the barrier of D + 1: no counted waits beyond that.
+//   * a wave's 64 couts x 64 pixels are 4 x 4 tiles of 16 x 16; row m of cout tile i is channel 16 (m >> 2) + 4 i + (m & 3), so the
+//     accumulator rows 4 g + r of the four tiles are 16 CONSECUTIVE channels 16 g + 4 i + r of the lane's pixel -- the epilogue needs
+//     no permlane swaps.  Pixel tile j: 2 rows x 8 columns at (+2 (j >> 1), +8 (j & 1)), lane n = 2x2 block n >> 2, pixel n & 3 of it.
+//   * weight rows in LDS are swizzled by (cout >> 4) & 3 (the 16 lanes of a k-group read couts 16 apart), pixels as above.
+// Not bit-identical to the kernels above (the taps are summed in another order); tests/test_gpu_conv_dma.py holds it to them within
+// the fp32 rounding of the sums and to float64 like every other stage.
+template <class Store>
+__device__ __forceinline__ void epilogue16_sh8_st(f32x4 (&acc)[4][4], const Store& st, const float* sb, float winv, int H, int W, int Cout, int yw, int xw, int n0,
+                                                  int lane) {
+    const int n = lane & 15, g = lane >> 4, ql = n & 3, blk = n >> 2;
+    const int c4 = Cout >> 2, ch0 = n0 + 16 * g;
+    const float* bp = sb + 16 * g;
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4), b2 = *reinterpret_cast<const f32x4*>(bp + 8),
+                b3 = *reinterpret_cast<const f32x4*>(bp + 12);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x8 v0, v1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            v0[r] = fmaxf(fma_winv(acc[0][j][r], winv, b0[r]), 0.f);
+            v0[4 + r] = fmaxf(fma_winv(acc[1][j][r], winv, b1[r]), 0.f);
+            v1[r] = fmaxf(fma_winv(acc[2][j][r], winv, b2[r]), 0.f);
+            v1[4 + r] = fmaxf(fma_winv(acc[3][j][r], winv, b3[r]), 0.f);
+        }
+        f16x8 hi0, lo0, hi1, lo1;
+        split8(v0, hi0, lo0);
+        split8(v1, hi1, lo1);
+        u32x4 q0 = __builtin_bit_cast(u32x4, hi0), q1 = __builtin_bit_cast(u32x4, lo0);
+        u32x4 q2 = __builtin_bit_cast(u32x4, hi1), q3 = __builtin_bit_cast(u32x4, lo1);
+        quad_transpose(q0, q1, q2, q3, ql);
+#pragma unroll
+        for (int sidx = 0; sidx < 4; ++sidx) {
+            const int oy = yw + 2 * (j >> 1) + (sidx >> 1), ox = xw + 8 * (j & 1) + 2 * blk + (sidx & 1);
+            st((oy * W + ox) * c4 + (ch0 >> 2) + ql, oy < H && ox < W && ch0 < Cout, sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3);
+        }
+    }
+}
+// pooled variant: pool the raw sums first (see epilogue_pool_sh8_st), then each quad lane finishes and stores ONE piece
+template <class Store>
+__device__ __forceinline__ void epilogue16_pool_sh8_st(f32x4 (&acc)[4][4], const Store& st, const float* sb, float winv, int H, int W, int Cout, int yw, int xw,
+                                                       int n0, int lane) {
+    const int n = lane & 15, g = lane >> 4, ql = n & 3, blk = n >> 2;
+    const int c4 = Cout >> 2, ch0 = n0 + 16 * g;
+    const int Ho = H >> 1, Wo = W >> 1;
+    const bool upper = (ql & 2) != 0, want_lo = (ql & 1) != 0;
+    const float* bp = sb + 16 * g + 8 * (ql >> 1);  // the 8 channels this lane stores
+    const f32x4 b0 = *reinterpret_cast<const f32x4*>(bp), b1 = *reinterpret_cast<const f32x4*>(bp + 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        f32x4 a[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = acc[i][j][r];
+                x = fmaxf(x, dpp_quad_xor1(x));
+                x = fmaxf(x, dpp_quad_xor2(x));
+                a[i][r] = x;
+            }
+        asm volatile("" : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]));  // opaque values: no dynamic indexing (scratch) for the selects
+        const f32x4 ga = upper ? a[2] : a[0], gc = upper ? a[3] : a[1];
+        f32x8 gv = {ga[0], ga[1], ga[2], ga[3], gc[0], gc[1], gc[2], gc[3]};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            gv[r] = fmaxf(fma_winv(gv[r], winv, b0[r]), 0.f);
+            gv[4 + r] = fmaxf(fma_winv(gv[4 + r], winv, b1[r]), 0.f);
+        }
+        f16x8 hi, lo;
+        split8(gv, hi, lo);
+        const u32x4 qh = __builtin_bit_cast(u32x4, hi), qlo = __builtin_bit_cast(u32x4, lo);
+        const u32x4 piece = {want_lo ? qlo[0] : qh[0], want_lo ? qlo[1] : qh[1], want_lo ? qlo[2] : qh[2], want_lo ? qlo[3] : qh[3]};
+        const int oy = (yw >> 1) + (j >> 1), ox = (xw >> 1) + 4 * (j & 1) + blk;
+        st((oy * Wo + ox) * c4 + (ch0 >> 2) + ql, oy < Ho && ox < Wo && ch0 < Cout, piece);
+    }
+}
+
+__device__ __forceinline__ f32x4 mfma16x32(f16x8 a, f16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+
+template <int WY, int WX, bool POOL>
+__global__ __launch_bounds__(512, 2) void conv3x3_pair_kernel(const ConvF16Args p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    static_assert(WY * WX == 8, "eight waves");
+    constexpr int TH = 4 * WY, TW = 16 * WX;
+    constexpr int PW = ((TW + 2 + 7) / 16) * 16 + 8;            // pixel pitch == 8 (mod 16)
+    constexpr int NSLOT = ((TH + 1) * PW + TW + 2) * 4;         // 16-byte slots of a halo tile (last row without its pitch padding)
+    constexpr int NIW = (NSLOT + 511) / 512;                    // halo DMA pieces per wave
+    constexpr int LP = (NSLOT + 8 * NIW - 1) / (8 * NIW);       // lanes (16-byte slots) per halo piece
+    constexpr int IN_SZ = 8 * NIW * LP;
+    constexpr int WS = 3 * 64 * 4, WR = 4;                      // weight stage: 3 taps x 64 couts x 4 pieces = 768 slots of 16 B
+    constexpr int NWA = 2, WLP = WS / (8 * NWA);                // ... moved as two 48-lane pieces per wave
+    constexpr int E = POOL ? 4 : 16;                            // output stores per wave and item
+    static_assert(LP <= 64 && E < 64, "vmcnt range");
+    __shared__ u32x4 s_all[2 * IN_SZ + WR * WS + CONV_DMA_MAXC / 4];
+    u32x4* const s_in = s_all;
+    u32x4* const s_w = s_all + 2 * IN_SZ;
+    float* const s_bias = reinterpret_cast<float*>(s_all + 2 * IN_SZ + WR * WS);
+
+    const int t = threadIdx.x, lane = t & 63;
+    const int wu = __builtin_amdgcn_readfirstlane(t >> 6);
+    const int tiles_x = (p.W + TW - 1) / TW, tiles_y = (p.H + TH - 1) / TH;
+    const int tiles = tiles_x * tiles_y, nslices = (p.Cout + 63) / 64;
+    const int total = tiles * nslices * p.B;
+    const int cin4 = p.Cin >> 2, nchunks = p.Cin >> 4;
+    const u32x4* in = reinterpret_cast<const u32x4*>(p.in);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p.Wt), 0, 0x7fffffff, 0x00020000);
+
+    struct Item { int b, y0, x0, n0; };
+    auto item_of = [&](int id) {
+        int logical = id;
+        if ((total & 7) == 0) logical = (id & 7) * (total >> 3) + (id >> 3);
+        const int slice = logical % nslices, r = logical / nslices;
+        const int tile = r % tiles;
+        return Item{r / tiles, (tile / tiles_x) * TH, (tile % tiles_x) * TW, slice * 64};
+    };
+
+    for (int i = t; i < CONV_DMA_MAXC; i += 512) s_bias[i] = i < p.Cout ? p.bias[i] : 0.f;
+
+    // DMA geometry (as in conv3x3_dma_kernel; the weight rows are swizzled by cout >> 4 here)
+    int in_off[NIW], in_yx[NIW], vo[NIW];
+#pragma unroll
+    for (int i = 0; i < NIW; ++i) {
+        const int gs = (wu + 8 * i) * LP + lane, P = gs >> 2, py = P / PW, px = P - py * PW;
+        const bool valid = gs < NSLOT && px < TW + 2;
+        in_off[i] = ((py * p.W + px) * cin4 + ((gs & 3) ^ ((P >> 2) & 3))) * 16;
+        in_yx[i] = valid ? (py << 16 | px) : -1;
+    }
+    auto set_vo = [&](const Item& it) {
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) {
+            const int py = in_yx[i] >> 16, px = in_yx[i] & 0xffff;
+            const bool ok = in_yx[i] >= 0 && (unsigned)(it.y0 + py - 1) < (unsigned)p.H && (unsigned)(it.x0 + px - 1) < (unsigned)p.W;
+            vo[i] = ok ? in_off[i] : (int)0x80000000;
+        }
+    };
+    int w_off[NWA];
+#pragma unroll
+    for (int i = 0; i < NWA; ++i) {
+        const int gs = (wu * NWA + i) * WLP + min(lane, WLP - 1), row = gs >> 2, tl = row >> 6, nn = row & 63;
+        w_off[i] = ((tl * p.CoutPad + nn) * 4 + ((gs & 3) ^ ((nn >> 4) & 3))) * 16;
+    }
+    auto in_rsrc = [&](const Item& it, int c) {
+        const u32x4* base = in + (((long long)it.b * p.H + (it.y0 - 1)) * p.W + (it.x0 - 1)) * cin4 + c * 4;
+        return __builtin_amdgcn_make_buffer_rsrc(const_cast<u32x4*>(base), 0, 0x7fffffff, 0x00020000);
+    };
+    auto dma_in = [&](const __amdgpu_buffer_rsrc_t& rs, int buf, int i) {
+        if (lane < LP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, s_in + buf * IN_SZ + (wu + 8 * i) * LP, 16, vo[i], 0, 0, 0);
+    };
+    auto dma_w = [&](int n0, int c, int ky, int slot, int i) {
+        const int soff = (((c * 9 + 3 * ky) * p.CoutPad + n0) * 4) * 16;
+        if (lane < WLP) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, s_w + slot * WS + (wu * NWA + i) * WLP, 16, w_off[i], soff, 0, 0);
+    };
+
+    // fragment geometry: byte offsets inside a halo tile / inside one tap's 64 x 64 B weight block
+    const int wy0 = (wu / WX) * 4, wx0 = (wu % WX) * 16;
+    const int n = lane & 15, g = lane >> 4, ch = g & 1;
+    const bool second = lane >= 32;
+    const int P00 = (wy0 + ((n >> 1) & 1)) * PW + wx0 + 2 * (n >> 2) + (n & 1);
+    int bk[3];
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) bk[kx] = ((P00 + kx) * 4 + ((2 * ch) ^ (((P00 + kx) >> 2) & 3))) * 16;
+    const int a0 = ((16 * (n >> 2) + (n & 3)) * 4 + ((2 * ch) ^ (n >> 2))) * 16;
+    const char* const lds = reinterpret_cast<const char*>(s_all);
+    constexpr int W_BASE = 2 * IN_SZ * 16;  // byte offset of the weight ring
+
+    f32x4 acc[4][4];
+    // Fragments of a pair: weights hi / lo of four cout tiles, pixels hi / lo of four pixel tiles.  Products run lo.hi, hi.lo, hi.hi, so
+    // A_lo is dead after the first and B_lo after the second: the next pair's A_lo / B_lo are read into the same registers under the
+    // second / third product, A_hi (first needed by the second product) under the pair's own first product, and only B_hi, live
+    // through the whole pair, has two register sets -- 80 fragment registers instead of 128.
+    f16x8 fah[4], fal[4], fbl[4], fbh[2][4];
+    int ax[2], bx[2][2];  // byte addresses of the pair being read: A hi / lo;  B [hi / lo][j & 1]
+
+    // tap T = 0..17 of a chunk pair: chunk parity T / 9 (= halo buffer), filter row, column, stage of its double stage
+    auto pair_addr = [&](auto kc, int wring) {  // addresses of pair K of the period; wring = byte offset of the double stage's two ring slots
+        constexpr int K = decltype(kc)::value;
+        constexpr int Ta = 2 * K, Tb = 2 * K + 1;
+        constexpr int cpa = Ta / 9, kya = (Ta % 9) / 3, kxa = Ta % 3, sta = (Ta / 3) & 1;
+        constexpr int cpb = Tb / 9, kyb = (Tb % 9) / 3, kxb = Tb % 3, stb = (Tb / 3) & 1;
+        const int fa = (bk[kxa] ^ ((kya & 1) << 5)) + (cpa * IN_SZ + kya * PW * 4) * 16;
+        const int fb = (bk[kxb] ^ ((kyb & 1) << 5)) + (cpb * IN_SZ + kyb * PW * 4) * 16;
+        const int sel = second ? fb : fa;
+        bx[0][0] = sel;
+        bx[1][0] = sel ^ 16;
+        bx[0][1] = (sel ^ 32) + 8 * 4 * 16;
+        bx[1][1] = bx[0][1] ^ 16;
+        const int wa = W_BASE + (sta * WS + kxa * 256) * 16, wb = W_BASE + (stb * WS + kxb * 256) * 16;
+        ax[0] = a0 + wring + (second ? wb : wa);
+        ax[1] = ax[0] ^ 16;
+    };
+    auto rd_a = [&](int lo, int i) { return *reinterpret_cast<const f16x8*>(lds + ax[lo] + i * 256); };
+    auto rd_b = [&](int lo, int j) { return *reinterpret_cast<const f16x8*>(lds + bx[lo][j & 1] + (j >> 1) * (2 * PW * 4 * 16)); };
+
+    int id = blockIdx.x;
+    if (id >= total) return;
+    Item cur = item_of(id);
+    // prologue: halo tile of chunk 0 -> buffer 0, weight stages (0, 0), (0, 1) -> ring slots 0, 1
+    set_vo(cur);
+    {
+        const __amdgpu_buffer_rsrc_t rs = in_rsrc(cur, 0);
+#pragma unroll
+        for (int i = 0; i < NIW; ++i) dma_in(rs, 0, i);
+#pragma unroll
+        for (int ky = 0; ky < 2; ++ky)
+#pragma unroll
+            for (int i = 0; i < NWA; ++i) dma_w(cur.n0, 0, ky, ky, i);
+    }
+    int D = 0;            // double stages of the stream so far (ring half = D & 1)
+    bool e_now = false;   // E output stores were issued after the last DMA request
+    for (;;) {
+        const bool more = id + (int)gridDim.x < total;
+        const Item nxt = item_of(more ? id + (int)gridDim.x : id);
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+        // double stage Q = 0, 1, 2 of the chunk pair (c, c + 1)
+        auto dstage = [&](auto qc, int c) {
+            constexpr int Q = decltype(qc)::value;
+            const bool last = c + 2 == nchunks;
+            // what double stage D + 1 needs: Q = 0 -> weight stages (c, 2), (c + 1, 0) and the halo tile of chunk c + 1 (buffer 1);
+            // Q = 1 -> (c + 1, 1), (c + 1, 2);  Q = 2 -> (c + 2, 0), (c + 2, 1) and the halo tile of chunk c + 2 (buffer 0) -- of the
+            // next item when this was the item's last chunk pair
+            const bool has_next = Q < 2 || !last || more;
+            const Item& nit = (Q == 2 && last) ? nxt : cur;
+            const int c0 = Q == 0 ? c : Q == 1 ? c + 1 : (last ? 0 : c + 2), ky0 = Q == 0 ? 2 : Q == 1 ? 1 : 0;
+            const int c1 = Q == 0 ? c + 1 : Q == 1 ? c + 1 : (last ? 0 : c + 2), ky1 = Q == 0 ? 0 : Q == 1 ? 2 : 1;
+            if (Q == 2 && last) set_vo(nxt);
+            const __amdgpu_buffer_rsrc_t rs = in_rsrc(nit, Q == 0 ? c + 1 : (last ? 0 : c + 2));
+            const int wring = (D & 1) * (2 * WS * 16), nslot = 2 * ((D + 1) & 1);
+
+            if (e_now) wait_vm_c<E>(); else wait_vm_c<0>();
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            e_now = false;
+            pair_addr(std::integral_constant<int, 3 * Q>{}, wring);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) { fal[r] = rd_a(1, r); fbh[0][r] = rd_b(0, r); }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) fbl[r] = rd_b(1, r);
+            PIN();
+            constexpr int ND = 2 * NWA + NIW;  // DMA requests of a double stage (all under its first pair)
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int S = k & 1;
+                const int d0 = k == 0 ? 4 : 0, p0 = k == 0 ? 4 + ND : 4;  // slots: [A_hi x 4][DMA][addresses of the next pair][B_hi' x 4] ... [16+: A_lo'] ... [32+: B_lo']
+                const int l0 = p0 + 5 > 16 ? p0 + 5 : 16;
+                static_assert(4 + ND + 5 + 4 <= 32, "filler slots");
+                int f = 0;
+                auto filler = [&]() {
+                    const int s = f++;
+                    if (s < 4) {
+                        fah[s] = rd_a(0, s);  // this pair's A_hi: first used by the second product
+                    } else if (k == 0 && s - d0 < ND) {
+                        const int d = s - d0;
+                        if (d < 2 * NWA) {
+                            if (has_next) dma_w(nit.n0, (d < NWA) ? c0 : c1, (d < NWA) ? ky0 : ky1, nslot + (d >= NWA), d % NWA);
+                        } else {
+                            if (Q != 1 && has_next) dma_in(rs, Q == 0 ? 1 : 0, d - 2 * NWA);
+                        }
+                    } else if (k < 2) {
+                        if (s == p0) {
+                            if (k == 0) pair_addr(std::integral_constant<int, 3 * Q + 1>{}, wring);
+                            else pair_addr(std::integral_constant<int, 3 * Q + 2>{}, wring);
+                        } else if (s > p0 && s <= p0 + 4) {
+                            fbh[1 - S][s - p0 - 1] = rd_b(0, s - p0 - 1);
+                        } else if (s >= l0 && s < l0 + 4) {
+                            fal[s - l0] = rd_a(1, s - l0);      // A_lo is dead after the first product
+                        } else if (s >= 32 && s < 36) {
+                            fbl[s - 32] = rd_b(1, s - 32);      // B_lo is dead after the second product
+                        }
+                    }
+                    PIN();
+                };
+                // lo.hi, hi.lo, hi.hi: consecutive MFMAs on different accumulators
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { acc[i][j] = mfma16x32(fal[i], fbh[S][j], acc[i][j]); filler(); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { acc[i][j] = mfma16x32(fah[i], fbl[j], acc[i][j]); filler(); }
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { acc[i][j] = mfma16x32(fah[i], fbh[S][j], acc[i][j]); filler(); }
+            }
+            ++D;
+        };
+#pragma unroll 1
+        for (int c = 0; c < nchunks; c += 2) {
+            dstage(std::integral_constant<int, 0>{}, c);
+            dstage(std::integral_constant<int, 1>{}, c);
+            dstage(std::integral_constant<int, 2>{}, c);
+        }
+        {
+            const float* sb = s_bias + cur.n0;
+            const int Ho = POOL ? p.H >> 1 : p.H, Wo = POOL ? p.W >> 1 : p.W;
+            const int img_bytes = Ho * Wo * p.Cout * 4;
+            BufStore st{__builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<char*>(p.out) + (long long)cur.b * img_bytes, 0, img_bytes, 0x00020000)};
+            if (POOL) epilogue16_pool_sh8_st(acc, st, sb, p.winv, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, cur.n0, lane);
+            else epilogue16_sh8_st(acc, st, sb, p.winv, p.H, p.W, p.Cout, cur.y0 + wy0, cur.x0 + wx0, cur.n0, lane);
+            e_now = true;
+        }
+        if (!more) break;
+        cur = nxt;
+        id += gridDim.x;
+    }
+#endif
+}
+
 // conv1a + conv1b + 2x2 max-pool in one kernel (superpoint.py:209-211): the 64-channel full-resolution
 // map of conv1a (78.6 MB per VGA image) never exists in HBM.  Per 16-channel chunk the conv1a outputs of
 // the 18x34 halo tile are recomputed from a 20x36 gray tile in LDS (VALU, weights in SGPRs: every wave
@@ -1419,13 +1742,24 @@ void launch_conv3x3_f16x3(const ConvF16Args& a, hipStream_t s) {
     const bool generic = !(a.relu && !a.out_f32 && !a.post_scale);  // BatchNorm affine / fp32 output / no ReLU
     // Hot layout (ReLU, SH8 out): the LDS-DMA kernel, 16x32 or 32x16 pixel tiles, one 8-wave workgroup per CU.
     // a.staged (debug request "sp.conv_staged", tests/test_gpu_conv_dma.py) keeps the register-staged kernel below.
-    const bool staged_only = a.staged != 0;
+    const bool staged_only = a.staged == 1;
     const long long out_img_bytes = (long long)(a.pool ? a.H / 2 : a.H) * (a.pool ? a.W / 2 : a.W) * a.Cout * 4;
     if (!generic && !staged_only && a.Cin % 32 == 0 && a.Cout % 4 == 0 && a.Cout <= CONV_DMA_MAXC && out_img_bytes < (1ll << 31) &&
         (!a.pool || (a.H % 2 == 0 && a.W % 2 == 0))) {
         const bool wide = w42 <= w81;
         const long long items = (wide ? (long long)((a.H + 15) / 16) * ((a.W + 31) / 32) : (long long)((a.H + 31) / 32) * ((a.W + 15) / 16)) * nslices * a.B;
         const dim3 grid((unsigned)std::min<long long>(items, cu_count()));
+        // a.staged == 2 (debug request "sp.conv_dma32"): the 32x32x16 LDS-DMA kernel instead of the tap-pair kernel (A/B runs, tests)
+        if (a.staged != 2) {
+            if (wide) {
+                if (a.pool) hipLaunchKernelGGL((conv3x3_pair_kernel<4, 2, true>), grid, dim3(CT), 0, s, a);
+                else hipLaunchKernelGGL((conv3x3_pair_kernel<4, 2, false>), grid, dim3(CT), 0, s, a);
+            } else {
+                if (a.pool) hipLaunchKernelGGL((conv3x3_pair_kernel<8, 1, true>), grid, dim3(CT), 0, s, a);
+                else hipLaunchKernelGGL((conv3x3_pair_kernel<8, 1, false>), grid, dim3(CT), 0, s, a);
+            }
+            return;
+        }
         if (wide) {
             if (a.pool) hipLaunchKernelGGL((conv3x3_dma_kernel<4, 2, true>), grid, dim3(CT), 0, s, a);
             else hipLaunchKernelGGL((conv3x3_dma_kernel<4, 2, false>), grid, dim3(CT), 0, s, a);

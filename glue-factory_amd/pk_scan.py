@@ -25,7 +25,7 @@ ALLOW = {
     "ffn_f16x3_kernel": "phase 2 (bias / LayerNorm / GELU / split) runs between the `__syncthreads()` that ends phase 1's stage loop and the "
                         "one that precedes phase 3's first MFMA; one workgroup per CU (158 KB of LDS), so no other workgroup's MFMAs share the SIMD",
 }
-NO_SCRATCH = ("conv3x3_dma_kernel", "conv1ab_mfma_kernel")  # counted vmcnt waits (conv_f16.hip)
+NO_SCRATCH = ("conv3x3_dma_kernel", "conv1ab_mfma_kernel", "conv3x3_pair_kernel")  # counted vmcnt waits (conv_f16.hip)
 _PK = re.compile(r"\bv_pk_(?:fma|mul|add)_f32\b")
 _MFMA = re.compile(r"\bv_mfma_")
 _FUNC = re.compile(r"^([A-Za-z_][\w$.]*):\s*(?:;.*)?$")

@@ -16,7 +16,8 @@ import sys
 SHORT = {
     "conv1ab_f16x3_kernel": "sp.conv1ab",
     "conv3x3_f16x3_kernel": "sp.conv3x3",
-    "conv3x3_dma_kernel": "sp.conv3x3",
+    "conv3x3_dma_kernel": "sp.conv3x3 (32x32x16 DMA)",
+    "conv3x3_pair_kernel": "sp.conv3x3",
     "conv1ab_dma_kernel": "sp.conv1ab",
     "conv1ab_mfma_kernel": "sp.conv1ab",
     "gemm_kernel<true, true>": "lg.gemm.sim (precise)",

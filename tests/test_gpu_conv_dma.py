@@ -1,8 +1,13 @@
 """The LDS-DMA convolutions against the register-staged kernels they replace.
 
-conv3x3_dma_kernel keeps the accumulation order of conv3x3_f16x3_kernel, so given the same input every encoder layer must be
-BIT-identical (SH8 words), on interior, border and ragged tiles, pooled and not, one and several tiles per workgroup: both runs take
-conv1b from the register-staged conv1ab kernel (debug request "sp.conv1ab_staged"), so all later layers see identical inputs.
+conv3x3_dma_kernel (debug request "sp.conv_dma32" since the tap-pair kernel ships) keeps the accumulation order of
+conv3x3_f16x3_kernel, so given the same input every encoder layer must be BIT-identical (SH8 words), on interior, border and ragged
+tiles, pooled and not, one and several tiles per workgroup: both runs take conv1b from the register-staged conv1ab kernel (debug
+request "sp.conv1ab_staged"), so all later layers see identical inputs.
+
+conv3x3_pair_kernel (16x16x32 MFMA, tap pairs as the contraction index: the shipped 3x3 kernel) sums the taps in another order, so it
+is held to the staged kernels within fp32 rounding of the sums (2e-5 of the layer's largest activation, through all eight layers) and
+must be bit-identical from run to run.
 
 conv1ab_mfma_kernel (round 3) evaluates conv1a on the matrix pipe with split-fp16 operands where the staged kernel uses fp32 FMAs: its
 conv1b output is held to 1e-4 ABSOLUTE of the float64 oracle (oracle/anchor.py; activations reach |x| ~ 10) on the same shapes, gray
@@ -27,8 +32,8 @@ def run_layers(img, dev, request, names=NAMES):
                                                   "force_num_keypoints": True, "dense_outputs": True}).eval()
     m.load_state_dict(O.make_sp_weights(0))
     eng = m.engine(dev)
-    if request:
-        eng.debug_request(request)
+    for r in ([request] if isinstance(request, str) else request or []):
+        eng.debug_request(r)
     for n in names:
         eng.debug_request("sp." + n)
     m({"image": img.to(dev)})
@@ -59,13 +64,35 @@ def test_dma_conv_bit_identical_to_staged(shape):
     dev = torch.device("cuda:0")
     img = _image(shape)
     a = run_layers(img, dev, "sp.conv_staged")      # every layer on the register-staged kernels
-    b = run_layers(img, dev, "sp.conv1ab_staged")   # conv1ab staged (identical conv1b), every 3x3 layer on conv3x3_dma_kernel
+    b = run_layers(img, dev, ("sp.conv1ab_staged", "sp.conv_dma32"))   # conv1ab staged (identical conv1b), every 3x3 layer on conv3x3_dma_kernel
     for n in NAMES:
         same = torch.equal(a[n], b[n])
         if not same:
             d = (a[n] != b[n]).nonzero().flatten()
             print(n, "differing words", d.numel(), "of", a[n].numel(), "first", d[:8].tolist())
         assert same, n
+
+
+@pytest.mark.parametrize("shape", SHAPES)
+def test_pair_conv_vs_staged(shape):
+    from test_gpu_sp_stages import decode_sh8
+
+    dev = torch.device("cuda:0")
+    B, H, W, C = shape
+    img = _image(shape)
+    a = run_layers(img, dev, "sp.conv_staged")
+    runs = [run_layers(img, dev, "sp.conv1ab_staged") for _ in range(2)]   # conv1b staged, every 3x3 layer on conv3x3_pair_kernel
+    h, w = H, W
+    for n in NAMES:
+        assert torch.equal(runs[0][n], runs[1][n]), f"{n}: conv3x3_pair_kernel is not deterministic"
+        cout = {"1": 64, "2": 64, "3": 128, "4": 128, "P": 256, "D": 256}[n[4]]
+        if n in ("conv1b", "conv2b", "conv3b"):
+            h, w = h // 2, w // 2
+        x = decode_sh8(a[n].view(torch.float32), (B, h, w, cout)).double()
+        y = decode_sh8(runs[0][n].view(torch.float32), (B, h, w, cout)).double()
+        err, top = float((x - y).abs().max()), float(x.abs().max())
+        print(f"  {n}: |pair - staged| max {err:.2e}  (|x| max {top:.2f})")
+        assert err <= 2e-5 * max(top, 1.0), (n, err, top)
 
 
 @pytest.mark.parametrize("shape", SHAPES)
