@@ -496,6 +496,16 @@ def main():
             "kernels_source": f"separate fully instrumented pass of {nb} steps before the timed region (an event pair per launch costs ~10 us of stream time; "
                               "the timed region carries the dominant kernel's pair only)",
         }
+        # the dominant kernel changes hands between runs when two are within a per cent of each other (round 3: lg.ffn 3.34 ms, sp.conv1ab
+        # 3.29 ms per step): the same figures for the four largest, from the breakdown pass, so that a reader sees all of them in every line
+        mult = 1 if args.precision == "f32" else 3
+        res["roofline_top"] = [
+            {"kernel": k, "ms_per_step": round(prof[k][0] / nb, 4), "launches_per_step": prof[k][1] // nb, "avg_launch_ms": round(prof[k][0] / prof[k][1], 4),
+             "achieved": round(flops[k] / (prof[k][0] / prof[k][1] * 1e-3) / 1e12, 2), "unit": "TFLOP/s",
+             "frac": round(flops[k] / (prof[k][0] / prof[k][1] * 1e-3) / 1e12 / PEAK[args.precision], 4),
+             "executed_frac": round(flops[k] / (prof[k][0] / prof[k][1] * 1e-3) / 1e12 * mult / PEAK[args.precision], 4),
+             "kernel_time_share": round(prof[k][0] / total_ms, 4)}
+            for k in sorted((k for k in prof if k in flops), key=lambda k: -prof[k][0])[:4]]
         att = [k for k in prof if ".attn." in k and k in flops]
         if att:  # the attention contractions (QK^T + PV) on their own: north_star asks for their MFMA utilisation
             a_ms = sum(prof[k][0] for k in att)
