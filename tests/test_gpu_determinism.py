@@ -44,3 +44,48 @@ def test_two_view_pipeline_is_deterministic(precision):
                 d = (a.float() - b.float()).abs()
                 print(k, "run", r, "differs: max", d.max().item(), "count", int((d > 0).sum()), "of", d.numel())
             assert same, (k, r)
+
+
+def _bit_equal(a, b):
+    if a.dtype.is_floating_point:
+        return torch.equal(a.contiguous().view(torch.uint8), b.contiguous().view(torch.uint8))
+    return torch.equal(a, b)
+
+
+def _assert_repeatable(module, data, runs=2):
+    outs = []
+    for _ in range(runs):
+        out = module(data)
+        torch.cuda.synchronize()
+        outs.append({k: v.clone() for k, v in out.items() if torch.is_tensor(v)})
+    for r in range(1, runs):
+        for k in sorted(outs[0]):
+            assert _bit_equal(outs[0][k], outs[r][k]), (k, r)
+    return outs[0]
+
+
+def test_superglue_is_deterministic():
+    """The ReLU variant of the fused FFN, the GNN's attention launches and the fused Sinkhorn iteration (per-row-block partials combined
+    in a fixed order), f16x3, one repeat: bit-identical outputs (the determinism guard covered SP + LightGlue only)."""
+    import test_gpu_superglue as T
+
+    dev = torch.device("cuda:0")
+    data = T._to(T._pairs(2, 1024, 1000, 5), dev)
+    out = _assert_repeatable(T._module(dev, O.make_sg_weights(9), 0.2, "f16x3"), data)
+    assert {"matches0", "matching_scores0", "log_assignment"} <= set(out)
+
+
+def test_gluestick_is_deterministic():
+    """Point + line GNN, line layers (gather / mean-scatter) and both double soft-max assignments, f16x3, one repeat: bit-identical."""
+    import importlib.util
+    import os
+
+    import test_gpu_gluestick as T
+
+    spec = importlib.util.spec_from_file_location("gs_inputs_src", os.path.join(os.path.dirname(__file__), "gs_inputs.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    dev = torch.device("cuda:0")
+    data = T._to(mod.gs_inputs(2, 600, 640, 120, 110, 3, corresponding=True), dev)
+    out = _assert_repeatable(T._module(O.make_gs_weights(4, **O.GS_GOLDEN), 0.2, "f16x3"), data)
+    assert {"matches0", "line_matches0", "log_assignment", "line_log_assignment"} <= set(out)
