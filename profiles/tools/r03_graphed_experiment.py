@@ -1,0 +1,99 @@
+"""ARCHIVED EXPERIMENT (round 3) -- not part of the package, not importable from here (it lived in gluefactory_amd/ and used an ABI 11
+entry point, mg_workspace_generation, that was removed with it).  Kept as the record of what was tried: DESIGN.md section 4,
+"hipGraph replay".  Original module text follows.
+"""
+"""hipGraph replay of a forward pass, for the launch-bound regime (one or a few pairs per call).
+
+At 32 pairs per step the path is kernel-bound (the ~100 launches of a step are queued far ahead of the GPU).  At ONE pair per call
+launch overhead is the obvious suspect -- and measured it is not the bound either: replaying the step as one graph takes a VGA pair
+from 3.89 to 3.79 ms (4 pairs: 4.75 -> 4.65 ms; 32 pairs: no change; `profiles/r03_g_graph_vs_eager.json`), because the fused kernels
+are tiled for throughput and a single pair leaves each of them a serial loop on a handful of workgroups (the fused FFN runs 16
+workgroups x ~90 us per launch whatever the batch).  The wrapper is kept for hosts whose CPU is the bottleneck (a replay costs one
+launch call instead of ~100).  `GraphedModule` captures one forward of a module of this package into a HIP graph (torch.cuda.CUDAGraph is
+hipGraph on ROCm: the native launches go to `torch.cuda.current_stream()`, which is the capture stream during capture, and torch's
+graph-private memory pool keeps every tensor the forward allocates at a fixed address) and replays it per call:
+
+    g = GraphedModule(pipe)            # pipe: a TwoViewPipeline / extractor / matcher of this package, weights loaded
+    out = g(data)                      # first call with a new input signature: 3 eager warm-up calls + capture; later calls: copy-in + replay
+
+Rules (they are what stream capture demands, nothing of ours):
+  * the forward must not synchronise with the host: use `force_num_keypoints: True` (or `sync_free`) in the extractor, and no adaptive
+    LightGlue (its depth / width decisions are read by the host every layer);
+  * inputs are copied into static tensors (one device copy per input tensor and call), outputs are the SAME tensors on every call --
+    consume or `.clone()` them before the next call;
+  * one graph per input signature (shapes and dtypes of all tensors in `data`), kept until `reset()` -- or until the native library
+    re-allocates workspace (a larger shape arrived, through this wrapper or through an eager call): the recorded kernel arguments
+    point into the old buffers then, so every graph remembers `mg_workspace_generation()` of its capture and is re-captured when the
+    counter has moved.
+There is no fallback: a forward that cannot be captured raises.
+"""
+import torch
+
+from . import _native
+
+
+def _flatten(d, prefix=""):
+    for k in sorted(d):
+        v = d[k]
+        if isinstance(v, dict):
+            yield from _flatten(v, prefix + k + "/")
+        elif torch.is_tensor(v):
+            yield prefix + k, v
+
+
+def _rebuild(d, tensors, prefix=""):
+    out = {}
+    for k, v in d.items():
+        if isinstance(v, dict):
+            out[k] = _rebuild(v, tensors, prefix + k + "/")
+        elif torch.is_tensor(v):
+            out[k] = tensors[prefix + k]
+        else:
+            out[k] = v
+    return out
+
+
+class GraphedModule:
+    WARMUP = 3  # eager calls before capture: workspaces of the native library are sized on first use (hipMalloc cannot be captured)
+
+    def __init__(self, module):
+        self.module = module.eval()
+        self._graphs = {}
+
+    def reset(self):
+        self._graphs.clear()
+
+    @staticmethod
+    def signature(data):
+        return tuple((k, tuple(v.shape), v.dtype, v.device.index) for k, v in _flatten(data))
+
+    def _capture(self, data):
+        static = {k: v.clone() for k, v in _flatten(data)}
+        static_data = _rebuild(data, static)
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side), torch.no_grad():
+            for _ in range(self.WARMUP):
+                self.module(static_data)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph), torch.no_grad():
+            out = self.module(static_data)
+        return graph, static, out, int(_native.lib().mg_workspace_generation())
+
+    def __call__(self, data):
+        sig = self.signature(data)
+        entry = self._graphs.get(sig)
+        if entry is not None and entry[3] != int(_native.lib().mg_workspace_generation()):
+            entry = None  # workspace moved since the capture (a larger shape somewhere): its recorded pointers are stale
+        if entry is None:
+            if not any(v.is_cuda for _, v in _flatten(data)):
+                raise RuntimeError("GraphedModule needs device-resident inputs (stream capture records device work only)")
+            self._graphs.pop(sig, None)
+            entry = self._graphs[sig] = self._capture(data)
+        graph, static, out, _ = entry
+        for k, v in _flatten(data):
+            static[k].copy_(v, non_blocking=True)
+        graph.replay()
+        return out
