@@ -141,7 +141,7 @@ struct mg_context {
     std::map<std::string, size_t> tap_count;
 
     bool profile = false;
-    std::string prof_filter;  // when not empty only the scope of that name is timed (mg_profile_filter)
+    std::string prof_filter;  // when not empty only the scope of that name, or of that dotted family, is timed (mg_profile_filter)
     std::vector<ProfEntry> prof;
     std::vector<hipEvent_t> event_pool;
     size_t event_used = 0;
@@ -168,7 +168,11 @@ struct ProfScope {
     hipStream_t s;
     size_t idx = 0;
     bool on;
-    ProfScope(mg_context* h_, hipStream_t s_, const char* name) : h(h_), s(s_), on(h_->profile && (h_->prof_filter.empty() || h_->prof_filter == name)) {
+    // the filter names one scope ("sp.conv1ab") or a dotted family ("lg.attn" = "lg.attn.self" + "lg.attn.cross": one GPU function)
+    static bool selected(const std::string& f, const char* name) {
+        return f.empty() || f == name || (std::strncmp(name, f.c_str(), f.size()) == 0 && name[f.size()] == '.');
+    }
+    ProfScope(mg_context* h_, hipStream_t s_, const char* name) : h(h_), s(s_), on(h_->profile && selected(h_->prof_filter, name)) {
         if (!on) return;
         ProfEntry e;
         e.name = name;

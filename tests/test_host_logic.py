@@ -286,3 +286,16 @@ def test_partial_checkpoints_leave_children_uninitialized():
     sp = get_model("superpoint")({})
     res = sp.load_state_dict({k: v for k, v in O.make_sp_weights(0).items() if not k.startswith("convDb")})
     assert res.missing_keys == ["convDb.bias", "convDb.weight"]
+
+
+def test_bench_kernel_families():
+    """bench.py judges dominance per GPU function: the self and cross launches of a layer are one attention kernel."""
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "bench.py"))
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert b.family("lg.attn.self") == b.family("lg.attn.cross") == "lg.attn"
+    assert b.family("sg.attn.cross") == "sg.attn" and b.family("gs.attn.self") == "gs.attn"
+    for k in ("sp.conv1ab", "lg.ffn", "lg.gemm.qkv", "lg.gemm.qkv_cross", "sp.conv2a"):
+        assert b.family(k) == k
