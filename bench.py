@@ -267,6 +267,8 @@ def main():
     ap.add_argument("--images", default="boat", choices=["boat", "noise"],
                     help="boat: SURVEY 8(d) tiling of the boat pair with circular shifts (default); noise: seeded smooth noise")
     ap.add_argument("--no-f32", action="store_true", help="skip the f32-mode sibling measurement")
+    ap.add_argument("--graph", action="store_true", help="replay the step as one HIP graph (gluefactory_amd/graphed.py): for small batches on a busy host, "
+                                                         "e.g. --pairs 1; the roofline then comes from the instrumented (eager) pass")
     ap.add_argument("--cpu-leg", default=None, help="internal: 'threads,batch' -- time one leg of the CPU oracle and print it as JSON (no GPU)")
     args = ap.parse_args()
     K = args.kpts
@@ -341,8 +343,15 @@ def main():
 
     gather_stats = {}
 
-    def step():
-        pred = pipe(data)
+    graphed = None
+    if args.graph:  # the whole step as one hipGraph replay; eager for the instrumented breakdown pass
+        if args.matcher != "lightglue":
+            raise SystemExit("--graph is verified for the SuperPoint + LightGlue path only (gluefactory_amd/graphed.py)")
+        from gluefactory_amd.graphed import GraphedModule
+        graphed = GraphedModule(pipe)
+
+    def step(eager=False):
+        pred = pipe(data) if (graphed is None or eager) else graphed(data)
         return all_gather_matches(pred, num_pairs=world * B, stats=gather_stats) if world > 1 else pred
 
     def note(msg):
@@ -376,7 +385,7 @@ def main():
         e.profile_filter(None)
         e.profile_enable(True)
     for _ in range(nb):
-        step()
+        step(eager=True)
     torch.cuda.synchronize()
     prof_all = read_prof()
     flops_tbl = algorithmic_flops(B)
@@ -392,7 +401,7 @@ def main():
     # is launched many times per step is sampled in every fourth step of the region only (>= 1 step; the steps are identical).
     dom_launches = sum(prof_all[k][1] for k in groups.get(dom_pre, [])) // nb if dom_pre is not None else 0
     ev_every = 1 if dom_launches <= 2 else 4
-    ev_on = not no_events and dom_pre is not None
+    ev_on = not no_events and dom_pre is not None and graphed is None  # (a captured graph holds no event pairs)
     for e in engines:
         e.profile_filter(dom_pre)
         e.profile_enable(ev_on)   # (clears the entries of the breakdown pass)
@@ -501,7 +510,7 @@ def main():
                                     f"SuperPoint + GlueStick, {W}x{H}, {K} kpts + {args.lines} synthetic segments, batch={B} pairs per GPU "
                                     "(BASELINE.json configs[4]; LSD itself is a CPU dependency and not timed)"),
                        "pairs_per_gpu": B, "pairs_per_rank": [B] * world, "global_pairs": B * world, "parallelism": f"dp{world}",
-                       "images": args.images, "matches_per_step_rank0": nvalid,
+                       "images": args.images, "matches_per_step_rank0": nvalid, "hip_graph_replay": bool(args.graph),
                        "all_gather": ({"collective": "all_gather_into_tensor (RCCL)", "calls_per_step": 1,
                                        "bytes_sent_per_rank": gather_stats.get("bytes_sent"), "bytes_received_per_rank": gather_stats.get("bytes_received")}
                                       if world > 1 else None),

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -40,11 +41,14 @@ struct HostTensor {
     }
 };
 
+static std::atomic<unsigned long long> g_ws_generation{0};  // mg_workspace_generation(): re-allocations of workspace so far
+
 struct DevBuf {
     void* p = nullptr;
     size_t bytes = 0;
     int ensure(size_t need) {
         if (need <= bytes) return 0;
+        g_ws_generation.fetch_add(1, std::memory_order_relaxed);
         if (p) {
             if (hipDeviceSynchronize() != hipSuccess) return -1;
             (void)hipFree(p);
@@ -766,6 +770,7 @@ int run_detect(mg_context* h, const mg_sp_conf* conf, const float* heat, int B, 
 extern "C" {
 
 int mg_abi_version(void) { return MG_ABI_VERSION; }
+unsigned long long mg_workspace_generation(void) { return g_ws_generation.load(std::memory_order_relaxed); }
 
 const char* mg_last_error(void) { return g_err.c_str(); }
 

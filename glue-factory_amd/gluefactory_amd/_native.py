@@ -19,7 +19,7 @@ MG_SAMPLE_LEGACY, MG_SAMPLE_FIXED, MG_SAMPLE_OPEN, MG_SAMPLE_CORNER = 0, 1, 2, 3
 
 # every symbol include/matchglue.h declares (checked by tests/test_abi.py)
 EXPORTS = [
-    "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_set_precision", "mg_set_weight", "mg_weights_ready",
+    "mg_create", "mg_destroy", "mg_last_error", "mg_abi_version", "mg_workspace_generation", "mg_set_precision", "mg_set_weight", "mg_weights_ready",
     "mg_sp_forward", "mg_sp_detect", "mg_sp_sample", "mg_lg_forward", "mg_lg_forward_adaptive", "mg_sg_forward", "mg_gs_forward", "mg_wf_filter", "mg_nn_forward", "mg_debug_request", "mg_debug_read",
     "mg_profile_enable", "mg_profile_filter", "mg_profile_read", "mg_test_linear", "mg_test_attention",
 ]
@@ -67,6 +67,8 @@ def lib():
         )
     L = ctypes.CDLL(LIB_PATH)
     L.mg_last_error.restype = c_char_p
+    L.mg_workspace_generation.restype = ctypes.c_ulonglong
+    L.mg_workspace_generation.argtypes = []
     L.mg_create.argtypes = [c_int, POINTER(c_void_p)]
     L.mg_destroy.argtypes = [c_void_p]
     L.mg_set_precision.argtypes = [c_void_p, c_int]

@@ -1,7 +1,3 @@
-"""ARCHIVED EXPERIMENT (round 3) -- not part of the package, not importable from here (it lived in gluefactory_amd/ and used an ABI 11
-entry point, mg_workspace_generation, that was removed with it).  Kept as the record of what was tried: DESIGN.md section 4,
-"hipGraph replay".  Original module text follows.
-"""
 """hipGraph replay of a forward pass, for the launch-bound regime (one or a few pairs per call).
 
 At 32 pairs per step the path is kernel-bound (the ~100 launches of a step are queued far ahead of the GPU).  At ONE pair per call
@@ -25,6 +21,9 @@ Rules (they are what stream capture demands, nothing of ours):
     re-allocates workspace (a larger shape arrived, through this wrapper or through an eager call): the recorded kernel arguments
     point into the old buffers then, so every graph remembers `mg_workspace_generation()` of its capture and is re-captured when the
     counter has moved.
+  * verified for the SuperPoint + LightGlue path (tests/test_gpu_graphed.py).  One pitfall of ROCm 7.2 found on the way: a
+    hipMemsetAsync recorded as a memset NODE was not ordered before the kernel after it, so the detect stage now clears its counters with
+    a kernel (sp_post.hip); SuperGlue's Sinkhorn and GlueStick's line layer still start from memsets and are NOT verified under replay.
 There is no fallback: a forward that cannot be captured raises.
 """
 import torch

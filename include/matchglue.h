@@ -65,8 +65,13 @@ int mg_create(int device, mg_handle* out);
 int mg_destroy(mg_handle h);
 const char* mg_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
-#define MG_ABI_VERSION 10 /* bumped whenever an entry point or a conf struct changes */
+#define MG_ABI_VERSION 11 /* bumped whenever an entry point or a conf struct changes */
 int mg_abi_version(void);   /* == MG_ABI_VERSION of the header the library was built from */
+/* Counts the re-allocations of handle-owned workspace in this process (workspaces grow on demand when a larger shape arrives, and a
+ * grown buffer is a NEW device address).  A caller that recorded the launches of a forward pass -- a hipGraph captured from the
+ * stream passed to mg_*_forward, gluefactory_amd/graphed.py -- must re-record once this value has changed: the recorded kernel
+ * arguments point into the old buffers.  Nothing in the reference corresponds to it (eager PyTorch). */
+unsigned long long mg_workspace_generation(void);
 
 /* -- arithmetic ------------------------------------------------------------------------------
  * MG_PREC_F32   : fp32-input MFMA everywhere (v_mfma_f32_32x32x2_f32), bit-for-bit an fp32 FMA chain.

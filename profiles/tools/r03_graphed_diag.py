@@ -1,11 +1,12 @@
-"""ARCHIVED DIAGNOSTIC (round 3) for the experiment in r03_graphed_experiment.py.  DO NOT RUN as is: in mode "sp" the replay on a new
-input ended in a GPU memory access fault (profiles/r03_g_graph_replay_diag.txt).
+"""Step-by-step check of hipGraph replay against the eager forward (modes: sp | lg | pipe), as run for profiles/r03_g_*diag*.txt:
+   python profiles/tools/r03_graphed_diag.py sp
+With the per-image counters of the detect stage cleared by hipMemsetAsync (a memset NODE in the graph) the sp mode returned stale
+candidates on new inputs and once faulted; cleared by a kernel (sp_post.hip: zero_ints_kernel) every replay is bit-identical.
 """
-"""Diagnostic for the hipGraph replay abort: step-by-step with prints (run on the GPU box with AMD_LOG_LEVEL=1)."""
 import sys, os
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", ".."))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), "..", "..", "glue-factory_amd"))
-sys.path.insert(0, os.path.join(os.path.dirname(__file__), ".."))
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "..")
+for q in (ROOT, os.path.join(ROOT, "glue-factory_amd"), os.path.join(ROOT, "tests")):
+    sys.path.insert(0, q)
 import torch
 import torch.nn.functional as F
 from oracle import sp_lg_oracle as O
