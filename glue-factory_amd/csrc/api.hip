@@ -1660,7 +1660,7 @@ int mg_nn_forward(mg_handle h, const mg_nn_conf* conf, const float* desc0, const
         const int Dp = (D + 15) & ~15;
         float* PD = h->buf("nn.pad", (T0 + T1) * Dp);
         if (!PD) return fail(MG_ERR_HIP, "workspace allocation failed");
-        HIPCHK(hipMemsetAsync(PD, 0, (T0 + T1) * Dp * sizeof(float), s));
+        launch_zero_words(PD, (size_t)(T0 + T1) * Dp, s);  // (a kernel, not a memset node: kernels.h)
         HIPCHK(hipMemcpy2DAsync(PD, Dp * sizeof(float), desc0, D * sizeof(float), D * sizeof(float), T0, hipMemcpyDeviceToDevice, s));
         HIPCHK(hipMemcpy2DAsync(PD + T0 * Dp, Dp * sizeof(float), desc1, D * sizeof(float), D * sizeof(float), T1, hipMemcpyDeviceToDevice, s));
         desc0 = PD;

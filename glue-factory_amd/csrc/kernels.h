@@ -172,6 +172,9 @@ struct DetectArgs {
     int* num_valid = nullptr;           // (B)
 };
 void launch_detect(const DetectArgs& a, hipStream_t s);
+// Zero `words` 32-bit words with a KERNEL (never hipMemsetAsync: as a memset node of a captured hipGraph it was not ordered before the
+// kernel that follows it on ROCm 7.2 -- sp_post.hip).
+void launch_zero_words(void* p, size_t words, hipStream_t s);
 struct SampleArgs {
     const float* keypoints = nullptr;  // (B,K,2) (x,y)+0.5
     const float* dense = nullptr;      // NHWC (B,hc,wc,256), normalised

@@ -366,7 +366,7 @@ void launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
     p.norm = -logf((float)a.M + (float)a.N);
     p.log_mu_bin = logf((float)a.N) + p.norm;
     p.log_nu_bin = logf((float)a.M) + p.norm;
-    (void)hipMemsetAsync(p.v, 0, sizeof(float) * a.B * p.vstride, s);
+    launch_zero_words(p.v, (size_t)a.B * p.vstride, s);  // (a kernel, not a memset node: kernels.h)
     const long long rows = (long long)a.B * (a.M + 1);
     const dim3 rgrid((unsigned)((rows + 3) / 4)), cgrid((a.N + 1 + 63) / 64, a.B);
     const bool fused = (a.N & 3) == 0 && a.N <= 2048 && (reinterpret_cast<uintptr_t>(a.cost) & 15) == 0;
@@ -386,7 +386,7 @@ void launch_sinkhorn(const SinkhornArgs& a, hipStream_t s) {
             hipLaunchKernelGGL(sinkhorn_cols_kernel, cgrid, dim3(64 * COLS_WAVES), 0, s, p);
         }
     }
-    if (a.iters == 0) (void)hipMemsetAsync(p.u, 0, sizeof(float) * a.B * (a.M + 1), s);
+    if (a.iters == 0) launch_zero_words(p.u, (size_t)a.B * (a.M + 1), s);
     hipLaunchKernelGGL(sinkhorn_final_rows, rgrid, dim3(256), 0, s, p, a.log_assignment, a.row_best, a.row_arg);
     hipLaunchKernelGGL(sinkhorn_final_cols, dim3((a.N + 63) / 64, a.B), dim3(256), 0, s, p, a.col_best, a.col_arg);
 }

@@ -388,11 +388,16 @@ void launch_nchw_to_nhwc(const float* in, float* out, int B, int HW, int C, hipS
 // node of ROCm 7.2 was not ordered before the NMS kernel that follows it -- a replay on new data mixed candidates of the previous image
 // into the list (results differed from the eager ones, one run ended in a memory access fault), while the same stream executed eagerly
 // is fine.  profiles/r03_g_graph_replay_diag.txt (memset) vs r03_g_diag_sp_zero_kernel.txt (kernel).
-__global__ void zero_ints_kernel(int* p, int n) {
-    for (int i = threadIdx.x; i < n; i += blockDim.x) p[i] = 0;
+__global__ void zero_ints_kernel(int* p, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0;
+}
+void launch_zero_words(void* p, size_t words, hipStream_t s) {
+    if (!words) return;
+    const unsigned blocks = (unsigned)std::min<size_t>((words + 255) / 256, 2048);
+    hipLaunchKernelGGL(zero_ints_kernel, dim3(blocks), dim3(256), 0, s, static_cast<int*>(p), words);
 }
 void launch_detect(const DetectArgs& a, hipStream_t s) {
-    hipLaunchKernelGGL(zero_ints_kernel, dim3(1), dim3(256), 0, s, a.counts, a.B * COUNT_STRIDE);
+    launch_zero_words(a.counts, (size_t)a.B * COUNT_STRIDE, s);
     const int per_img = ((a.Ws + NMS_TILE - 1) / NMS_TILE) * ((a.Hs + NMS_TILE - 1) / NMS_TILE);
     dim3 grid((unsigned)(8 * ((a.B + 7) / 8) * per_img));  // id -> (XCD = id % 8, image group, tile), see nms_kernel
     switch (a.radius) {

@@ -23,7 +23,7 @@ Rules (they are what stream capture demands, nothing of ours):
     counter has moved.
   * verified for the SuperPoint + LightGlue path (tests/test_gpu_graphed.py).  One pitfall of ROCm 7.2 found on the way: a
     hipMemsetAsync recorded as a memset NODE was not ordered before the kernel after it, so the detect stage now clears its counters with
-    a kernel (sp_post.hip); SuperGlue's Sinkhorn and GlueStick's line layer still start from memsets and are NOT verified under replay.
+    a kernel (sp_post.hip: launch_zero_words, used for every buffer the library clears); SuperGlue / GlueStick are NOT verified under replay.
 There is no fallback: a forward that cannot be captured raises.
 """
 import torch
