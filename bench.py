@@ -153,12 +153,36 @@ def cores_evidence():
     return ev
 
 
-def cpu_baseline(matcher="lightglue", images="boat", budget_s=60.0, note=lambda m: None, only=None):
+def all_cores_leg(matcher, images, limit=45.0):
+    """The leg of the CPU baseline on ALL visible cores, needed only where no cgroup quota says what this process may use.  It runs in a
+    child process with a hard time limit (on a box whose share of the host is smaller than what it sees, hundreds of threads time-slice
+    each other: 177 s for one batch-8 pass on 256 threads against 4.8 s on 16) -- and main() calls this BEFORE its first torch.cuda call:
+    a process that has initialised HIP starts no child on this pool.  Returns a leg dict, or None when a quota defines the share.  No
+    failure of the child (refused spawn, time-out, garbage) may cost the run its JSON line: it is recorded in the leg instead."""
+    import subprocess
+
+    cores, cores_seen, cores_source = usable_cores()
+    if cores_seen <= cores or cores_source.startswith("cgroup"):
+        return None
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{cores_seen},1", "--matcher", matcher, "--images", images,
+           "--kpts", str(K), "--size", f"{W}x{H}"]
+    t0 = time.perf_counter()
+    try:
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit).stdout.strip().splitlines()
+        return json.loads(out[-1])
+    except Exception as e:  # TimeoutExpired, OSError (spawn refused), IndexError / ValueError (no JSON line)
+        why = (f"did not complete one warm-up pass + one timed pass within {limit:.0f} s ({time.perf_counter() - t0:.0f} s waited): "
+               f"slower than {1.0 / (limit / 2):.3f} pairs/s, i.e. below the {cores}-thread legs") if isinstance(e, subprocess.TimeoutExpired) \
+            else f"leg not run: {type(e).__name__}: {e}"
+        return {"batch": 1, "threads": cores_seen, "pairs_per_s": 0.0, "median_s": None, "reps": 0, "warmup": 0, "note": why}
+
+
+def cpu_baseline(matcher="lightglue", images="boat", budget_s=60.0, note=lambda m: None, only=None, extra_leg=None):
     """The CPU oracle (oracle/sp_lg_oracle.py, a restatement of the reference) on a bounded sample of the same workload,
     SURVEY 8(d) protocol: B = 1 and B = 8, 3 warm-up + >= 10 timed repetitions each, time.perf_counter, median, on the threads
     `usable_cores()` gives: the cgroup CPU quota where one is set (it IS the box's share; stated in `cores_share_source`), else a 16-core
-    share plus a leg on ALL visible cores in a time-limited child process, so that the reported value is the best the host does either
-    way (`value` = the fastest leg, `cores` = its thread count).  A repetition count is cut
+    share plus a leg on ALL visible cores (`extra_leg`, timed by `all_cores_leg` in a time-limited child process before the GPU work), so
+    that the reported value is the best the host does either way (`value` = the fastest leg, `cores` = its thread count).  A repetition count is cut
     (and said so in `sample`) only if the leg would pass its budget."""
     from oracle import sp_lg_oracle as O
 
@@ -204,26 +228,12 @@ def cpu_baseline(matcher="lightglue", images="boat", budget_s=60.0, note=lambda 
         med = statistics.median(times)
         return {"batch": batch, "threads": cores, "pairs_per_s": round(batch / med, 4), "median_s": round(med, 4), "reps": len(times), "warmup": warm}
 
-    if only is not None:  # child process of the all-cores leg below
+    if only is not None:  # child process of the all-cores leg (all_cores_leg)
         return run(only[1], only[0], budget_s=budget_s)
     legs = [run(1, cores), run(8, cores)]
-    if cores_seen > cores and not cores_source.startswith("cgroup"):
-        # no quota tells what this process may use: time every visible core too, in a child process with a hard time limit: on a box whose share of the host is smaller than what it sees,
-        # hundreds of threads time-slice each other (first run here: 177 s for one batch-8 pass on 256 threads against 4.8 s on 16)
-        import subprocess
-
-        limit = 45.0
-        cmd = [sys.executable, os.path.abspath(__file__), "--cpu-leg", f"{cores_seen},1", "--matcher", matcher, "--images", images,
-               "--kpts", str(K), "--size", f"{W}x{H}"]
-        t0 = time.perf_counter()
-        try:
-            out = subprocess.run(cmd, capture_output=True, text=True, timeout=limit).stdout.strip().splitlines()
-            legs.append(json.loads(out[-1]))
-        except (subprocess.TimeoutExpired, IndexError, ValueError):
-            legs.append({"batch": 1, "threads": cores_seen, "pairs_per_s": 0.0, "median_s": None, "reps": 0, "warmup": 0,
-                         "note": f"did not complete one warm-up pass + one timed pass within {limit:.0f} s ({time.perf_counter() - t0:.0f} s waited): "
-                                 f"slower than {1.0 / (limit / 2):.3f} pairs/s, i.e. below the {cores}-thread legs"})
-        note(f"cpu oracle, all {cores_seen} visible cores: {legs[-1]}")
+    if extra_leg is not None:  # the all-visible-cores leg, timed by main() BEFORE this process initialised HIP
+        legs.append(extra_leg)
+        note(f"cpu oracle, all {cores_seen} visible cores (timed before the GPU run): {extra_leg}")
     best = max(legs, key=lambda l: l["pairs_per_s"])
     return {"value": best["pairs_per_s"], "unit": "pairs/s", "cores": best["threads"], "cores_visible": cores_seen, "cores_share": cores,
             "cores_share_source": cores_source, "cores_evidence": cores_evidence(), "kind": "port", "cpu": cpu_model(),
@@ -282,6 +292,11 @@ def main():
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         launch_ranks(args)  # does not return
+    # the one child process of a single-GPU run (all-visible-cores CPU leg; only where no cgroup quota defines the CPU share) is started
+    # and finished here, before anything below initialises HIP
+    extra_leg = None
+    if args.gpus == 1 and not args.no_cpu_baseline and args.matcher != "gluestick":
+        extra_leg = all_cores_leg(args.matcher, args.images)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -562,7 +577,7 @@ def main():
             res["f32_mode"] = f32_mode
         if world == 1 and not args.no_cpu_baseline:
             note("timing the CPU oracle (B = 1 and B = 8 on the core share, + all visible cores when no cgroup quota defines the share; 3 warm-up + up to 10 repetitions each, 1-2 min)")
-            cb = cpu_baseline(matcher=args.matcher, images=args.images, note=note)
+            cb = cpu_baseline(matcher=args.matcher, images=args.images, note=note, extra_leg=extra_leg)
             if cb is not None:
                 res["cpu_baseline"] = cb
         print(json.dumps(res), flush=True)

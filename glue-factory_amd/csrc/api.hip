@@ -41,7 +41,10 @@ struct HostTensor {
     }
 };
 
-static std::atomic<unsigned long long> g_ws_generation{0};  // mg_workspace_generation(): re-allocations of workspace so far
+// mg_workspace_generation(): bumped by everything that makes the arguments or the kernel selection of a recorded launch sequence stale --
+// a workspace re-allocation, the release of a model's device weights before a re-tiling (load_state_dict), a precision change, a new
+// debug request (they select kernel variants).  A hipGraph captured at generation g may only be replayed while the counter still reads g.
+static std::atomic<unsigned long long> g_ws_generation{0};
 
 struct DevBuf {
     void* p = nullptr;
@@ -205,6 +208,7 @@ int upload(mg_context* h, const std::vector<float>& v, float** out) {
 // sync: launches of the old weights may still be in flight on some stream).
 int begin_prepare(mg_context* h, int which) {
     h->cur_which = which;
+    g_ws_generation.fetch_add(1, std::memory_order_relaxed);  // recorded launches point at the weight buffers released below
     if (h->owned[which].empty()) return 0;
     HIPCHK(hipDeviceSynchronize());
     for (void* q : h->owned[which]) (void)hipFree(q);
@@ -801,6 +805,7 @@ int mg_destroy(mg_handle h) {
 
 int mg_set_precision(mg_handle h, int mode) {
     if (!h || (mode != MG_PREC_F32 && mode != MG_PREC_F16X3)) return fail(MG_ERR_ARG, "bad precision mode");
+    if (h->precision != mode) g_ws_generation.fetch_add(1, std::memory_order_relaxed);  // other kernels, other buffers
     h->precision = mode;
     return 0;
 }
@@ -826,6 +831,7 @@ int mg_weights_ready(mg_handle h, int which, int variant_or_layers) {
 
 int mg_debug_request(mg_handle h, const char* tap) {
     if (!h || !tap) return fail(MG_ERR_ARG, "bad argument");
+    if (h->taps.find(tap) == h->taps.end()) g_ws_generation.fetch_add(1, std::memory_order_relaxed);  // requests select kernel variants / add taps
     h->taps[tap];
     return 0;
 }

@@ -189,8 +189,13 @@ __global__ __launch_bounds__(NMS_THREADS) void nms_kernel(const DetectArgs p) {
     if (cnt == 0) return;
     if (threadIdx.x == 0) s_base = atomicAdd(&p.counts[b * COUNT_STRIDE], cnt);
     __syncthreads();
-    unsigned long long* dst = p.cand + (long long)b * p.Hs * p.Ws + s_base;
-    for (int i = threadIdx.x; i < cnt; i += NMS_THREADS) dst[i] = s_cand[i];
+    // The per-image list holds Hs*Ws entries, which a correct run can never exceed (one candidate per pixel at most).  The append is
+    // clamped to that capacity all the same: a counter that was NOT zero when the launch started (the unordered memset node of a graph
+    // replay, round 3) then costs wrong candidates, never a write outside the list.
+    const int cap = p.Hs * p.Ws, base = s_base;
+    unsigned long long* dst = p.cand + (long long)b * cap;
+    for (int i = threadIdx.x; i < cnt; i += NMS_THREADS)
+        if (base >= 0 && base + i < cap) dst[base + i] = s_cand[i];
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -208,7 +213,7 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const DetectArgs p)
     __shared__ int s_want, s_cnt;
 
     const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
-    const int n = p.counts[b * COUNT_STRIDE];
+    const int n = min(max(p.counts[b * COUNT_STRIDE], 0), p.Hs * p.Ws);  // never read past the list (see the clamped append in nms_kernel)
     const int K = p.K;
     const unsigned long long* cand = p.cand + (long long)b * p.Hs * p.Ws;
     int P = 1;

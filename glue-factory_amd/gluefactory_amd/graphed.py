@@ -17,10 +17,12 @@ Rules (they are what stream capture demands, nothing of ours):
     LightGlue (its depth / width decisions are read by the host every layer);
   * inputs are copied into static tensors (one device copy per input tensor and call), outputs are the SAME tensors on every call --
     consume or `.clone()` them before the next call;
-  * one graph per input signature (shapes and dtypes of all tensors in `data`), kept until `reset()` -- or until the native library
-    re-allocates workspace (a larger shape arrived, through this wrapper or through an eager call): the recorded kernel arguments
-    point into the old buffers then, so every graph remembers `mg_workspace_generation()` of its capture and is re-captured when the
-    counter has moved.
+  * one graph per input signature (shapes and dtypes of all tensors in `data`), kept until `reset()` -- or until something a recorded
+    launch depends on has changed: the native library re-allocated workspace (a larger shape arrived, through this wrapper or through
+    an eager call), released a model's device weights for a re-tiling, switched precision or took a new debug request (all counted by
+    `mg_workspace_generation()`), or a module below received new weights / another precision that it has not uploaded yet (uploads
+    happen lazily in the eager forward, which a replay never runs: `_module_state()`).  Every graph remembers both values of its
+    capture and is re-captured when either has moved.
   * verified for the SuperPoint + LightGlue path (tests/test_gpu_graphed.py).  One pitfall of ROCm 7.2 found on the way: a
     hipMemsetAsync recorded as a memset NODE was not ordered before the kernel after it, so the detect stage now clears its counters with
     a kernel (sp_post.hip: launch_zero_words, used for every buffer the library clears); SuperGlue / GlueStick are NOT verified under replay.
@@ -62,6 +64,14 @@ class GraphedModule:
     def reset(self):
         self._graphs.clear()
 
+    def _module_state(self):
+        """What the recorded launches of the native modules below depend on besides the library's own generation counter: the weight
+        set each holds (`load_state_dict` bumps `_weights_version`; the upload itself is lazy) and its precision conf."""
+        from .base_model import NativeModel
+
+        return tuple((name, m._weights_version, str(m.conf.get("precision", "f16x3")))
+                     for name, m in self.module.named_modules() if isinstance(m, NativeModel))
+
     @staticmethod
     def signature(data):
         return tuple((k, tuple(v.shape), v.dtype, v.device.index) for k, v in _flatten(data))
@@ -79,13 +89,13 @@ class GraphedModule:
         graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(graph), torch.no_grad():
             out = self.module(static_data)
-        return graph, static, out, int(_native.lib().mg_workspace_generation())
+        return graph, static, out, (int(_native.lib().mg_workspace_generation()), self._module_state())
 
     def __call__(self, data):
         sig = self.signature(data)
         entry = self._graphs.get(sig)
-        if entry is not None and entry[3] != int(_native.lib().mg_workspace_generation()):
-            entry = None  # workspace moved since the capture (a larger shape somewhere): its recorded pointers are stale
+        if entry is not None and entry[3] != (int(_native.lib().mg_workspace_generation()), self._module_state()):
+            entry = None  # workspace / weights / kernel selection moved since the capture: its recorded launches are stale
         if entry is None:
             if not any(v.is_cuda for _, v in _flatten(data)):
                 raise RuntimeError("GraphedModule needs device-resident inputs (stream capture records device work only)")

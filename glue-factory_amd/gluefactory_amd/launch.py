@@ -59,6 +59,7 @@ def launch_ranks(n_ranks, cmd, n_devices="auto", poll_s=0.05, grace_s=5.0):
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: what RCCL needs on this driver
         procs.append(subprocess.Popen(cmd, env=env))
     rc = 0
+    kill_at = None  # set at the first failure: ranks still alive `grace_s` later ignored SIGTERM (stuck in a collective / a GPU wait)
     try:
         pending = set(range(n_ranks))
         while pending:
@@ -72,6 +73,12 @@ def launch_ranks(n_ranks, cmd, n_devices="auto", poll_s=0.05, grace_s=5.0):
                     print(f"launch: rank {r} exited with {code}; stopping the other ranks", file=sys.stderr)
                     for q in pending:
                         procs[q].terminate()
+                    kill_at = time.time() + grace_s
+            if kill_at is not None and pending and time.time() >= kill_at:
+                for q in sorted(pending):
+                    print(f"launch: rank {q} ignored SIGTERM for {grace_s:g} s; killing it", file=sys.stderr)
+                    procs[q].kill()
+                kill_at = float("inf")  # SIGKILL cannot be ignored: the loop ends as soon as the kernel has reaped them
             time.sleep(poll_s)
     finally:
         t_end = time.time() + grace_s

@@ -67,10 +67,12 @@ const char* mg_last_error(void);
 /* ABI version of this header (bumped on any signature change). */
 #define MG_ABI_VERSION 11 /* bumped whenever an entry point or a conf struct changes */
 int mg_abi_version(void);   /* == MG_ABI_VERSION of the header the library was built from */
-/* Counts the re-allocations of handle-owned workspace in this process (workspaces grow on demand when a larger shape arrives, and a
- * grown buffer is a NEW device address).  A caller that recorded the launches of a forward pass -- a hipGraph captured from the
- * stream passed to mg_*_forward, gluefactory_amd/graphed.py -- must re-record once this value has changed: the recorded kernel
- * arguments point into the old buffers.  Nothing in the reference corresponds to it (eager PyTorch). */
+/* Counts, in this process, every event that makes a RECORDED launch sequence stale: a re-allocation of handle-owned workspace
+ * (workspaces grow on demand when a larger shape arrives, and a grown buffer is a NEW device address), the release of a model's
+ * device weights before they are re-tiled (mg_weights_ready after new mg_set_weight calls), a change of mg_set_precision, a new
+ * mg_debug_request (requests select kernel variants).  A caller that recorded the launches of a forward pass -- a hipGraph captured
+ * from the stream passed to mg_*_forward, gluefactory_amd/graphed.py -- must re-record once this value has changed: the recorded
+ * kernel arguments point into old buffers or name other kernels.  Nothing in the reference corresponds to it (eager PyTorch). */
 unsigned long long mg_workspace_generation(void);
 
 /* -- arithmetic ------------------------------------------------------------------------------

@@ -54,6 +54,35 @@ def test_graphed_pipeline_equals_eager(precision):
     assert len(g._graphs) == 2 and int(_native.lib().mg_workspace_generation()) > gen0
 
 
+def test_graphed_follows_load_state_dict_and_precision():
+    """New weights (or another precision) between two graphed calls: the replay must not run the launches recorded for the old weight
+    buffers -- neither before the eager path has uploaded the new set (stale result) nor after (freed buffers)."""
+    from gluefactory_amd.graphed import GraphedModule
+    from gluefactory_amd.two_view_pipeline import TwoViewPipeline
+
+    dev = torch.device("cuda:0")
+    pipe = TwoViewPipeline({"extractor": {"name": "gluefactory_nonfree.superpoint", "max_num_keypoints": 256, "nms_radius": 3, "detection_threshold": 0.0,
+                                          "force_num_keypoints": True},
+                            "matcher": {"name": "matchers.lightglue", "filter_threshold": 0.1}}).eval()
+    pipe.extractor.load_state_dict(O.make_sp_weights(0))
+    pipe.matcher.load_state_dict(O.make_lg_weights(7, structured=True, final_gain=3.0, match_bias=2.0))
+    g = GraphedModule(pipe)
+    data = _pair(5, 1, 240, 320, dev)
+    first = {k: v.clone() for k, v in g(data).items() if torch.is_tensor(v)}
+    # (a) new weights, replay BEFORE any eager forward has uploaded them
+    pipe.extractor.load_state_dict(O.make_sp_weights(1))
+    out = {k: v.clone() for k, v in g(data).items() if torch.is_tensor(v)}
+    eager = {k: v.clone() for k, v in pipe(data).items() if torch.is_tensor(v)}
+    assert all(_same(out[k], eager[k]) for k in eager)
+    assert not _same(out["keypoint_scores0"], first["keypoint_scores0"])
+    # (b) new weights, an eager forward re-tiles them (the old device buffers are freed), then the graphed call
+    pipe.matcher.load_state_dict(O.make_lg_weights(8, structured=True, final_gain=3.0, match_bias=2.0))
+    eager = {k: v.clone() for k, v in pipe(data).items() if torch.is_tensor(v)}
+    out = g(data)
+    torch.cuda.synchronize()
+    assert all(_same(out[k], eager[k]) for k in eager)
+
+
 def test_graphed_needs_device_inputs():
     from gluefactory_amd import get_model
     from gluefactory_amd.graphed import GraphedModule

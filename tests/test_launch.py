@@ -73,6 +73,32 @@ def test_launcher_stops_siblings_when_a_rank_dies(tmp_path):
     assert res.stdout.strip() == "" and "rank 1 exited with 7" in res.stderr
 
 
+def test_launcher_kills_a_rank_that_ignores_sigterm(tmp_path):
+    """A sibling stuck where SIGTERM does not reach it (a collective, a GPU wait) must not keep the launcher alive: after the grace
+    period it is killed and the first failing rank's exit code is still what the launcher leaves with."""
+    child = _stub(tmp_path, """
+        import os, signal, sys, time
+        if int(os.environ["RANK"]) == 1:
+            time.sleep(0.5)
+            sys.exit(7)
+        signal.signal(signal.SIGTERM, signal.SIG_IGN)
+        time.sleep(600)
+    """)
+    code = f"""
+import sys, time
+sys.path.insert(0, {os.path.join(ROOT, 'glue-factory_amd')!r})
+from gluefactory_amd.launch import launch_ranks
+t0 = time.time()
+rc = launch_ranks(2, {child!r}, n_devices=2, grace_s=1.0)
+print("elapsed", time.time() - t0)
+sys.exit(rc)
+"""
+    res = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=60)
+    assert res.returncode == 7, (res.returncode, res.stderr)
+    assert "ignored SIGTERM" in res.stderr
+    assert float(res.stdout.split()[-1]) < 30
+
+
 def test_launcher_refuses_when_devices_are_missing(tmp_path):
     child = _stub(tmp_path, "print('must not start')")
     res = _run_launcher(tmp_path, 4, child, 2)
@@ -110,6 +136,11 @@ def test_bench_parent_never_calls_torch_cuda():
     assert "torch.cuda" not in body
     main = src[src.index("def main():"):]
     assert main.index("launch_ranks(args)") < main.index("torch.cuda")
+    # the single-GPU run's only child process (all-visible-cores CPU leg) is also started before the first torch.cuda call, and the
+    # CPU-baseline code that runs after the GPU work spawns nothing
+    assert main.index("all_cores_leg(") < main.index("torch.cuda")
+    cb = src[src.index("def cpu_baseline("):src.index("def launch_ranks(args):")]
+    assert "subprocess" not in cb and "Popen" not in cb
     assert "torch" not in open(os.path.join(ROOT, "glue-factory_amd", "gluefactory_amd", "launch.py")).read().split('"""', 2)[2]
 
 
