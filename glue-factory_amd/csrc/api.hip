@@ -216,6 +216,15 @@ int begin_prepare(mg_context* h, int which) {
     return 0;
 }
 
+// which attention kernel the f16x3 mode launches: 0 = attention_pw_f16.hip (default), 1 = the round-1 8-wave kernel (debug request
+// "lg.attn8"), 16 + N = timing ablation N of the default kernel (debug request "lg.attn.exp<N>": wrong results on purpose, bench A/B only)
+int attn_variant(mg_context* h) {
+    if (h->taps.count("lg.attn8")) return 1;
+    for (auto& kv : h->taps)
+        if (kv.first.rfind("lg.attn.exp", 0) == 0) return 16 + atoi(kv.first.c_str() + 11);
+    return 0;
+}
+
 const HostTensor* find(mg_context* h, int which, const std::string& key) {
     auto it = h->raw[which].find(key);
     return it == h->raw[which].end() ? nullptr : &it->second;
@@ -1166,7 +1175,7 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         if (f16) {
             AttnF16Args a;
             a.q = QKV; a.k = QKV; a.v = QKV; a.ld = ld; a.q_col = 0; a.k_col = kcol; a.v_col = vcol;
-            a.out = CTX; a.ldo = 256; a.B = B; a.M = Mc; a.N = Nc; a.heads = 4; a.cross = cross;
+            a.out = CTX; a.ldo = 256; a.B = B; a.M = Mc; a.N = Nc; a.heads = 4; a.cross = cross; a.variant = attn_variant(h);
             launch_attention_f16x3(a, s);
         } else {
             AttnArgs a;
@@ -1391,7 +1400,7 @@ struct GnnRun {
             if (f16) {
                 AttnF16Args a;
                 a.q = QKV; a.k = QKV; a.v = QKV; a.ld = 768; a.q_col = 0; a.k_col = 256; a.v_col = 512;
-                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+                a.out = CTX; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross; a.variant = attn_variant(h);
                 launch_attention_f16x3(a, s);
             } else {
                 AttnArgs a;
@@ -1756,7 +1765,7 @@ int mg_test_attention(mg_handle h, const float* q, const float* k, const float* 
         launch_to_sh8(v, VS, (long long)T * 256, 1.f, s);
         AttnF16Args a;
         a.q = QS; a.k = KS; a.v = VS; a.ld = 256; a.q_col = 0; a.k_col = 0; a.v_col = 0;
-        a.out = OS; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross;
+        a.out = OS; a.ldo = 256; a.B = B; a.M = M; a.N = N; a.heads = 4; a.cross = cross; a.variant = attn_variant(h);
         launch_attention_f16x3(a, s);
         launch_from_sh8(OS, out, (long long)T * 256, s);
     } else {

@@ -222,6 +222,7 @@ __global__ __launch_bounds__(AT, 2) void attention_f16x3_kernel(const AttnF16Arg
 }  // namespace
 
 void launch_attention_f16x3(const AttnF16Args& a, hipStream_t s) {
+    if (a.variant != 1) return launch_attention_f16x3_pw(a, s);
     const int L = a.M > a.N ? a.M : a.N;
     dim3 grid((L + 8 * QW - 1) / (8 * QW), a.heads, 2 * a.B);
     hipLaunchKernelGGL(attention_f16x3_kernel, grid, dim3(AT), 0, s, a);

@@ -214,8 +214,11 @@ struct AttnF16Args {
     int B = 0, M = 0, N = 0;
     int heads = 4;
     int cross = 0;
+    int variant = 0;          // 0: attention_pw_f16.hip; 1: the round-1 kernel (8 waves, two per SIMD; debug request "lg.attn8");
+                              // 16 + N: timing ablation N of the pw kernel (debug request "lg.attn.exp<N>", wrong results on purpose)
 };
-void launch_attention_f16x3(const AttnF16Args& a, hipStream_t s);
+void launch_attention_f16x3(const AttnF16Args& a, hipStream_t s);       // dispatches on a.variant
+void launch_attention_f16x3_pw(const AttnF16Args& a, hipStream_t s);    // 4 waves, one per SIMD, software-pipelined (attention_pw_f16.hip)
 
 // ---- lg_misc.hip ---------------------------------------------------------------------------------
 void launch_posenc(const float* kpts0, const float* kpts1, const float* size0, const float* size1, const float* Wr,

@@ -1,0 +1,114 @@
+// Micro-benchmark (not part of the product): what fits into the shadow of a v_mfma_f32_32x32x16_f16 when ONE wave per SIMD issues both
+// the MFMAs and the vector work (the regime of attention_pw_f16.hip).  One workgroup of 256 threads per CU; every wave loops over
+// 8 x { MFMA (two alternating accumulators); NF fillers } and the cost is read in SHADER cycles (s_memtime) per MFMA.  Varied: the
+// accumulator file of the MFMA (arch VGPRs, as the S chains of the attention kernel, or AGPRs, as its O chains), the filler kind and
+// the number of fillers per gap.  Fillers rotate over 8 registers (dependency distance 8) except in the "dependent" kinds, which chain
+// every filler on the previous one -- the latency a single wave cannot hide.
+//     hipcc --offload-arch=gfx950 -O3 -o mfma_gap mfma_gap.hip && ./mfma_gap
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <vector>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+enum { F_ADD = 0, F_EXP = 1, F_MIX = 2, F_ADD_DEP = 3, F_EXP_DEP = 4, F_SOFTMAX = 5, F_LDS = 6, F_CVT = 7 };
+
+template <int ACC_AGPR, int KIND, int NF>
+__global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, float* sink, int iters) {
+    __shared__ float lds[4096];
+    for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i * 0.001f;
+    __syncthreads();
+    f32x16 acc0, acc1;
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    f16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(0.01f * ((threadIdx.x * 7 + j * 13) % 97)); b[j] = (_Float16)(0.02f * ((threadIdx.x * 11 + j * 5) % 89)); }
+    float r[8];
+    for (int i = 0; i < 8; ++i) r[i] = 0.001f * (threadIdx.x + 1) + 0.37f * i;
+    float c = 0.999f;
+    const float* lp = lds + (threadIdx.x & 63) * 4;
+    float4 ld = {0, 0, 0, 0};
+    unsigned long long t0, t1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    for (int it = 0; it < iters; ++it) {
+#pragma unroll
+        for (int g = 0; g < 8; ++g) {
+            if (ACC_AGPR) {
+                if (g & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc1) : "v"(a), "v"(b));
+                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc0) : "v"(a), "v"(b));
+            } else {
+                if (g & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
+                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
+            }
+#pragma unroll
+            for (int f = 0; f < NF; ++f) {
+                const int i = (g * NF + f) & 7;
+                if (KIND == F_ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+                else if (KIND == F_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
+                else if (KIND == F_MIX) asm volatile("v_fma_mixlo_f16 %0, %0, -1.0, %1 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(r[i]) : "v"(c));
+                else if (KIND == F_CVT) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+                else if (KIND == F_ADD_DEP) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[0]) : "v"(c));
+                else if (KIND == F_EXP_DEP) asm volatile("v_exp_f32 %0, %0" : "+v"(r[0]));
+                else if (KIND == F_SOFTMAX) {  // the attention mix: of every 5 fillers one exp, two adds, one cvt, one mix (independent)
+                    const int k = f % 5;
+                    if (k == 0) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
+                    else if (k == 1 || k == 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+                    else if (k == 3) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
+                    else asm volatile("v_fma_mixlo_f16 %0, %0, -1.0, %1 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(r[i]) : "v"(c));
+                } else if (KIND == F_LDS) {
+                    asm volatile("ds_read_b128 %0, %1" : "=v"(ld) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const float*)lp) : "memory");
+                }
+            }
+        }
+        if (KIND == F_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    float s = ld.x + ld.y;
+    for (int i = 0; i < 8; ++i) s += r[i];
+    for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 4 + (threadIdx.x >> 6)] = t1 - t0;
+}
+
+template <int ACC_AGPR, int KIND, int NF>
+static double run(int iters) {
+    unsigned long long* d;
+    float* sink;
+    hipMalloc(&d, 256 * 4 * 8);
+    hipMalloc(&sink, 4096);
+    hipLaunchKernelGGL((gap_kernel<ACC_AGPR, KIND, NF>), dim3(256), dim3(256), 0, 0, d, sink, iters);
+    hipLaunchKernelGGL((gap_kernel<ACC_AGPR, KIND, NF>), dim3(256), dim3(256), 0, 0, d, sink, iters);
+    std::vector<unsigned long long> h(1024);
+    hipMemcpy(h.data(), d, 1024 * 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    hipFree(sink);
+    std::sort(h.begin(), h.end());
+    return (double)h[512] / (8.0 * iters);  // median over the 1024 waves: shader cycles per MFMA gap
+}
+
+template <int KIND>
+static void row(const char* name) {
+    const int it = 4000;
+    printf("%-34s VGPR acc:", name);
+    printf(" %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f |", run<0, KIND, 0>(it), run<0, KIND, 2>(it), run<0, KIND, 3>(it), run<0, KIND, 4>(it), run<0, KIND, 5>(it),
+           run<0, KIND, 6>(it), run<0, KIND, 8>(it));
+    printf(" AGPR acc: %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f %5.1f\n", run<1, KIND, 0>(it), run<1, KIND, 2>(it), run<1, KIND, 3>(it), run<1, KIND, 4>(it),
+           run<1, KIND, 5>(it), run<1, KIND, 6>(it), run<1, KIND, 8>(it));
+}
+
+int main() {
+    printf("shader cycles per MFMA gap (v_mfma_f32_32x32x16_f16, one wave per SIMD); fillers per gap: 0 2 3 4 5 6 8\n");
+    row<F_ADD>("v_add_f32 (independent)");
+    row<F_EXP>("v_exp_f32 (independent)");
+    row<F_MIX>("v_fma_mixlo_f16 (independent)");
+    row<F_CVT>("v_cvt_pkrtz_f16_f32 (independent)");
+    row<F_SOFTMAX>("soft-max mix exp/add/add/cvt/mix");
+    row<F_ADD_DEP>("v_add_f32 (one dependent chain)");
+    row<F_EXP_DEP>("v_exp_f32 (one dependent chain)");
+    row<F_LDS>("ds_read_b128");
+    hipError_t e = hipDeviceSynchronize();
+    printf("status %s\n", hipGetErrorString(e));
+    return e != hipSuccess;
+}

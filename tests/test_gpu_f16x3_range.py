@@ -169,7 +169,10 @@ def make_qkv(kind, B, M, N, g):
 
 
 @pytest.mark.parametrize("cross", [False, True])
-@pytest.mark.parametrize("kind,B,M,N", [("diffuse", 2, 300, 517), ("peaked_pm40", 1, 2048, 2048), ("flat_tail_11", 1, 2048, 2048), ("flat_tail_17", 1, 2048, 2048), ("wide_v", 1, 1024, 999)])
+@pytest.mark.parametrize("kind,B,M,N", [("diffuse", 2, 300, 517), ("peaked_pm40", 1, 2048, 2048), ("flat_tail_11", 1, 2048, 2048), ("flat_tail_17", 1, 2048, 2048), ("wide_v", 1, 1024, 999),
+                                        # round 4 (attention_pw_f16.hip: software-pipelined key loop with a prologue, a peeled last iteration and a masked partial
+                                        # tile): one to four key tiles, full and partial, fewer queries than a wave / a workgroup holds
+                                        ("diffuse", 3, 5, 31), ("diffuse", 2, 32, 33), ("diffuse", 2, 70, 64), ("diffuse", 1, 257, 65), ("peaked_pm40", 2, 96, 97), ("peaked_pm40", 1, 128, 130)])
 def test_attention_against_fp64_bound(engine, dev, kind, B, M, N, cross):
     g = torch.Generator().manual_seed(len(kind) + M)
     q, k, v = make_qkv(kind, B, M, N, g)
