@@ -245,6 +245,57 @@ def cpu_baseline(matcher="lightglue", images="boat", budget_s=60.0, note=lambda 
                        f"; value = the fastest leg (batch {best['batch']}, {best['threads']} threads)")}
 
 
+class PowerSampler:
+    """Board power and shader clock read from the amdgpu hwmon / sysfs files of the rank's device while the timed region runs (a thread
+    that only reads files: no child process, nothing on the GPU).  Evidence for the power-limited regime DESIGN.md describes: the board
+    sits near 90 % of its cap and the clock the chip holds is what gives.  Every field is None where the files are not readable."""
+
+    def __init__(self, index):
+        import glob
+        import threading
+
+        self.samples, self.clocks, self._stop = [], [], threading.Event()
+        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/power1_average")) or \
+            sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/power1_input"))
+        self.path = cards[index] if index < len(cards) else None
+        self.cap = None
+        if self.path:
+            try:
+                self.cap = int(open(os.path.join(os.path.dirname(self.path), "power1_cap")).read()) / 1e6
+            except (OSError, ValueError):
+                pass
+            self.sclk = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(self.path))), "pp_dpm_sclk")
+        self._thread = threading.Thread(target=self._run, daemon=True)
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                self.samples.append(int(open(self.path).read()) / 1e6)
+                for line in open(self.sclk):
+                    if line.rstrip().endswith("*"):
+                        self.clocks.append(int("".join(ch for ch in line.split(":")[1] if ch.isdigit())))
+            except (OSError, ValueError, IndexError):
+                pass
+            self._stop.wait(0.05)
+
+    def __enter__(self):
+        if self.path:
+            self._thread.start()
+        return self
+
+    def __exit__(self, *a):
+        self._stop.set()
+        if self.path:
+            self._thread.join(timeout=1.0)
+
+    def summary(self):
+        if not self.samples:
+            return None
+        s, c = sorted(self.samples), sorted(self.clocks)
+        return {"board_power_w_median": round(s[len(s) // 2], 1), "board_power_w_max": round(s[-1], 1), "power_cap_w": self.cap, "samples": len(s),
+                "sclk_mhz_median": (c[len(c) // 2] if c else None), "source": "amdgpu hwmon power1_average / pp_dpm_sclk, sampled every 50 ms over the timed region"}
+
+
 def launch_ranks(args):
     """Parent of a stand-alone `--gpus N` run: start one rank per device and relay rank 0's JSON line (gluefactory_amd/launch.py).
     Nothing on this path initialises HIP: the devices are counted from the KFD topology in sysfs, the children are fresh processes."""
@@ -423,16 +474,18 @@ def main():
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        if ev_on and ev_every > 1:   # pause / resume through the filter (a name no scope has): enable / disable would drop the entries
-            for e in engines:
-                e.profile_filter(dom_pre if i % ev_every == 0 else "-")
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
+    power = PowerSampler(local_rank)
+    with power:
+        t0 = time.perf_counter()
+        for i in range(args.steps):
+            if ev_on and ev_every > 1:   # pause / resume through the filter (a name no scope has): enable / disable would drop the entries
+                for e in engines:
+                    e.profile_filter(dom_pre if i % ev_every == 0 else "-")
+            step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -573,6 +626,8 @@ def main():
             res["sinkhorn"] = {"ms_per_step": round(ms, 4), "iterations": it, "floor_bytes_per_step": floor,
                                "floor_definition": "B x (K+1)^2 x 4 B read once per iteration (superglue.py:173-201: 50 iterations, two half-steps each)",
                                "achieved_GBps_vs_floor_bytes": round(floor / (ms * 1e-3) / 1e9, 1), "hbm_peak_GBps": 8000.0}
+        if power.summary() is not None:
+            res["power"] = power.summary()
         if f32_mode is not None:
             res["f32_mode"] = f32_mode
         if world == 1 and not args.no_cpu_baseline:

@@ -13,7 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIBDIR = os.path.join(HERE, "lib")
 LIB = os.path.join(LIBDIR, "libmatchglue.so")
-SOURCES = ["api.hip", "gemm.hip", "conv.hip", "conv_f16.hip", "gemm_f16.hip", "attention_f16.hip", "attention_pw_f16.hip", "sg_misc.hip", "nn_misc.hip", "gs_misc.hip", "sp_post.hip", "attention.hip", "lg_misc.hip", "ffn_f16.hip", "wf_misc.hip", "heads_f16.hip"]
+SOURCES = ["api.hip", "gemm.hip", "conv.hip", "conv_f16.hip", "gemm_f16.hip", "gemm_ws_f16.hip", "attention_f16.hip", "attention_pw_f16.hip", "sg_misc.hip", "nn_misc.hip", "gs_misc.hip", "sp_post.hip", "attention.hip", "lg_misc.hip", "ffn_f16.hip", "wf_misc.hip", "heads_f16.hip"]
 # -packed-fp32-ops: no compiler-generated v_pk_*_f32.  On gfx950 a packed-fp32 instruction that broadcasts an operand half through
 # op_sel / op_sel_hi returned wrong low halves, nondeterministically, while MFMAs were executing on the same SIMD (conv_f16.hip:
 # conv1ab_dma_kernel, tests/test_gpu_determinism.py); the one place that wants packed FMAs writes them as inline asm on real pairs.
@@ -26,7 +26,7 @@ SOURCES = ["api.hip", "gemm.hip", "conv.hip", "conv_f16.hip", "gemm_f16.hip", "a
 # feeds a conversion there (o * 1/l in the epilogue) passes through inline asm first, so it exists as a rounded fp32 register.
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-Wall", "-Wno-unused-function"]
 NO_MIX = ["-Xclang", "-target-feature", "-Xclang", "-fma-mix-insts"]
-MIX_ON = {"attention_f16.hip", "attention_pw_f16.hip"}
+MIX_ON = {"attention_f16.hip", "attention_pw_f16.hip", "gemm_ws_f16.hip"}
 # conv_f16.hip is built with -fno-honor-nans: under IEEE mode every fmaxf(a, b) is preceded by canonicalising v_max_f32 x, x, x of its
 # inputs and the quad-DPP moves of the 2x2 max-pool stay separate instructions; without NaNs to honour hipcc emits ONE v_max_f32_dpp per
 # pooling step and one v_max per ReLU -- 384 of the ~1200 VALU instructions of a pooled tile epilogue, which no MFMA hides
@@ -53,6 +53,7 @@ def _stale():
 def build(force=False, verbose=True):
     # the filler schedule of attention_pw_f16.hip is generated (and committed): regenerate first, the file only changes when the generator did
     subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_attention_pw_sched.py")], stdout=subprocess.DEVNULL)
+    subprocess.check_call([sys.executable, os.path.join(CSRC, "gen_gemm_ws_sched.py")], stdout=subprocess.DEVNULL)
     if not force and not _stale():
         return LIB
     os.makedirs(LIBDIR, exist_ok=True)

@@ -1159,6 +1159,7 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         ProfScope ps(h, s, name);
         if (f16) {
             GemmF16Args g = lin_args_f16(blk.proj, XS, 256, (int)T);
+            g.generic_only = h->taps.count("lg.gemm_generic") ? 1 : 0;  // A/B and bit-identity tests of gemm_ws_f16.hip
             g.Cs = QKV; g.ldcs = ncols;
             if (rotary) { g.enc = ENC; g.rotary_cols = 512; }
             g.scale = scale; g.scale_cols = 256;
@@ -1212,6 +1213,7 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
         const LgBlock& sb = h->lg_self[i];
         // f16x3: log2(e) is folded into the logit scale so the attention kernel uses bare v_exp_f32
         proj(sb, "lg.gemm.qkv", 768, f16 ? 0.125f * 1.4426950408889634f : 0.125f, true);
+        if (i == 0) { if (int rc = tap_copy(h, "lg.qkv0", QKV, T * 768, s)) return rc; }  // raw rows of the first projection (SH8 words in f16x3 mode): kernel-equivalence tests
         attend("lg.attn.self", 768, 256, 512, 0);
         outproj(sb);
         ffn(sb);
@@ -1354,6 +1356,7 @@ struct GnnRun {
     void linear(const LinLayer& L, size_t rows, const float* A, int lda, const float* A1, int lda1, float* act_out, int ld_out, const Opt& o) const {
         if (f16) {
             GemmF16Args g = lin_args_f16(L, A, lda, (int)rows);
+            g.generic_only = h->taps.count("lg.gemm_generic") ? 1 : 0;
             if (A1) { g.A1 = A1; g.lda1 = lda1; g.ksplit = lda; }
             g.Cs = act_out; g.ldcs = ld_out; g.C = o.c32; g.ldc = o.ldc32;
             g.relu = o.relu; g.scale = o.scale; g.scale_cols = o.scale_cols; g.residual = o.residual; g.ldr = 256;

@@ -1,30 +1,45 @@
 // Flash-style attention, split-fp16 (SH8) operands, ONE WAVE PER SIMD with the whole 512-entry register file
-// (same math as attention_f16.hip: lightglue.py:105-115 self, :200-210 cross).
+// (same math as attention_f16.hip: lightglue.py:105-115 self, :200-210 cross).  The default attention kernel of the f16x3 mode since
+// round 4; attention_f16.hip (8 waves, two per SIMD) stays behind the debug request "lg.attn8".
 //
 // Why a second kernel.  attention_f16.hip runs two waves per SIMD in lockstep behind one barrier per key tile; inside a wave the
-// chain S -> max -> exp -> split -> PV is serial, so while a wave runs its ~1 200 cycles of soft-max VALU work it issues no MFMA and
-// its partner is in the same phase: 46 % MFMA-busy over three rounds and six re-arrangements, all of which died of the 256-register
-// limit (spills, LDS re-reads).  The way out the guide describes (cdna_hip_programming.md, Appendix B "4-wave, one-wave-per-SIMD,
-// persistent structure") is the opposite budget: a workgroup of FOUR waves, one per SIMD, each with up to 512 registers (arch VGPRs +
-// accumulator file), and the overlap done INSIDE the wave by software pipelining -- the matrix pipe executes tile t+1's QK^T while the
-// vector pipe finishes tile t's soft-max, and tile t's PV while tile t+1's row maxima are taken.  One MFMA occupies the pipe for 32
-// cycles and the vector issue port for 8 of them: every MFMA gap hides ~24 cycles of other instructions, i.e. ~5 plain VALU or one
-// v_exp_f32 + 3-4 (MI355X_MICROARCH.md, cycle constants).  Per 32-key tile a wave issues 48 MFMAs (1 536 cycles) and ~165 VALU +
-// 24 LDS reads + 4 LDS-DMA pieces (~1 150 cycles of issue): on paper the loop is matrix-bound.
+// chain S -> max -> exp -> split -> PV is serial, and six re-arrangements over three rounds all died of the 256-register limit
+// (spills, LDS re-reads).  The structure the guide describes (cdna_hip_programming.md, Appendix B "4-wave, one-wave-per-SIMD,
+// persistent structure") spends the opposite budget: a workgroup of FOUR waves, one per SIMD, each with up to 512 registers (arch
+// VGPRs + accumulator file), and the overlap done INSIDE the wave by software pipelining -- the matrix pipe executes tile t+1's QK^T
+// while the vector pipe finishes tile t's soft-max, and tile t's PV while tile t+1's row maxima are taken.  One MFMA occupies the
+// pipe for 32 cycles and the vector issue port for 8 of them: every MFMA gap hides ~24 cycles of other instructions -- five plain VALU
+// or three v_exp / v_fma_mix, measured (tests/micro/mfma_gap.hip, profiles/r04_f_mfma_gap.txt) -- provided they do not wait for each
+// other: a single wave has nobody to cover a dependency stall (a dependent v_add costs 8 cycles, a dependent v_exp 12).
 //
-// Structure (per workgroup: 256 queries of one (image, head); a wave owns 64 = two 32-query MFMA tiles):
-//   * K and V tiles (32 keys x 256 B each) arrive by LDS-DMA (buffer_load ... lds: rows past the sequence end are out of the buffer's
-//     range and land as zeros), 2-deep rings, K three tiles ahead of its use, V one; one barrier per key tile.
-//   * S'^T = K Q^T - m_off: the running offset sits in a 16-register block that is the C operand of the first MFMA of every chain, so
-//     the accumulator comes out ready for v_exp_f32 -- no subtraction, and the masking of a partial last tile is a -inf in that block.
+// What it bought, measured (profiles/r04_h_attn_pmc.txt, r04_i_*): 451 k -> 388 k shader cycles per launch (MFMA-busy 0.44 -> 0.51), but
+// the clock the chip holds falls with it, 2.17 -> 1.92 GHz: 208 -> 202 us in the stand-alone entry, 1.90 -> 1.83 ms per step for the nine
+// layers in bench.py.  The launch time of every variant is the SUM of what its parts cost alone (MFMAs only 131 us, + LDS / DMA 23,
+// + soft-max VALU 48 = 202): the board sits at ~1 260 W of its 1 400 W limit during the step (profiles/r04_i_power.txt) and the
+// kernel is bound by ENERGY, not by the schedule -- see DESIGN.md, round 4.  The kernel is kept because it is the faster one and
+// because its machinery (asm-owned accumulator classes, LDS-DMA rings with counted waits, generated per-instruction schedules) is
+// what the other matrix kernels can reuse; further gains here need fewer operations per tile, not a better order of the same ones.
+//
+// Structure (per block: 256 queries of one (image, head); a wave owns 64 = two 32-query MFMA tiles; one PERSISTENT workgroup per CU
+// walks the blocks of its XCD, the blocks of one (image, head) adjacent so that their K / V rows come out of one L2):
+//   * K and V tiles (32 keys x 256 B each) arrive by LDS-DMA written as asm (buffer_load_dwordx4 ... lds: invisible to hipcc's waitcnt
+//     insertion, which otherwise drains vmcnt to 0 in front of every later LDS read; rows past the sequence end are out of the
+//     descriptor's range and land as zeros).  3-deep rings, tile tau in slot tau % 3; iteration kt requests K(kt+4) and V(kt+2) and
+//     waits, at its top, for everything but its predecessor's four pieces (vmcnt retires in order): two iterations of flight.
+//   * S^T = K Q^T as asm MFMAs with the accumulators in arch VGPRs (hipcc puts every MFMA builtin of a > 256-register kernel into the
+//     accumulator file: 64 v_accvgpr moves per tile for a tile the soft-max reads element by element); Q fragments live in AGPRs
+//     ("a" operands), O accumulates through builtins in AGPRs and is never touched by the vector pipe inside the loop.
+//   * Masking of a partial last tile: the first MFMA of its chains takes a C operand with -inf in the rows of keys past the end.
 //   * V is consumed through ds_read_b64_tr_b16 (the hardware transpose read of gfx950): the LDS image is the plain row copy the DMA
-//     writes, no 2-byte transposing stores.
+//     writes, no 2-byte transposing stores; the swizzle (row & 1) | ((row & 2) << 2) on the piece index makes the 32 lanes of a half
+//     cover the 64 banks exactly once (SQ_LDS_BANK_CONFLICT = 0).
 //   * P' = 2^7 exp2(s - m_run) split hi/lo in registers and used directly as the B operand of O^T += V^T P^T (accumulator-as-operand;
 //     element j of lane half h is key 16 s + 8 (j >> 2) + 4 h + (j & 3), which is the row order the transposed reads deliver).
-//   * The running maximum is raised only when a query outgrows it by 2^8 (wave-uniform branch, after the PV MFMAs of the tile).
-//   * Phase 1 of iteration t: 24 MFMAs of S(t+1) || exp / row sums / split of S(t) (first three quarters) || V(t) reads || DMA issue.
-//     Phase 2: 24 MFMAs of PV(t) || last quarter of the split || row maxima of S(t+1) || K(t+2) reads.
-//   Every MFMA is followed by its share of the fillers and a sched_barrier: the order in the source is the order in the binary.
+//   * The running offset is raised only when a query outgrows it by 2^8 (wave-uniform branch after the tile's PV MFMAs); four partial
+//     row sums per query tile (register r adds to r & 3) keep the adds of a gap independent.
+//   * Iteration kt = 48 MFMAs: 24 of S(kt+1), then 24 of PV(kt).  Every other instruction of the iteration is a micro-op of the
+//     generated table attention_pw_sched.inc (gen_attention_pw_sched.py: costs, dependencies at >= one gap distance, deadlines), placed
+//     behind a fixed MFMA and fenced by sched_barriers: the order in the table is the order in the binary.
 #include <type_traits>
 #include <utility>
 

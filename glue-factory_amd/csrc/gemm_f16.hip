@@ -390,6 +390,7 @@ __global__ __launch_bounds__(256) void from_sh8_kernel(const void* __restrict__ 
 }  // namespace
 
 void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
+    if (!a0.generic_only && launch_gemm_ws_f16x3(a0, s)) return;  // the QKV projections (K = 256): weights stationary in registers
     GemmF16Args a = a0;
     // two 4-wave workgroups per CU (TOKW = 2; the 8-wave tile of round 1 measured 1-5 % slower)
     constexpr int tokw = 2;

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void gs_ds_rows(const GsSoftmaxArgs p) {
     }
     if (lane == 0) {
         p.row_best[(long long)b * p.M + i] = best;
-        p.row_arg[(long long)b * p.M + i] = arg;
+        p.row_arg[(long long)b * p.M + i] = arg < p.N ? arg : 0;  // (never an index outside the row: a row of NaNs leaves the sentinel, and the mutual check below indexes with this value)
     }
 }
 __global__ __launch_bounds__(256) void gs_ds_cols(const GsSoftmaxArgs p) {
@@ -200,7 +200,7 @@ __global__ __launch_bounds__(256) void gs_ds_cols(const GsSoftmaxArgs p) {
         for (int k = 1; k < 4; ++k)
             if (s_b[k][cl] > best || (s_b[k][cl] == best && s_a[k][cl] < arg)) { best = s_b[k][cl]; arg = s_a[k][cl]; }
         p.col_best[(long long)b * p.N + j] = best;
-        p.col_arg[(long long)b * p.N + j] = arg;
+        p.col_arg[(long long)b * p.N + j] = arg < p.M ? arg : 0;
     }
 }
 

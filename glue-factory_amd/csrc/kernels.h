@@ -114,8 +114,10 @@ struct GemmF16Args {
     int batch = 1;
     long long strideA = 0, strideW = 0, strideC = 0, strideCs = 0;  // elements
     int stagger = 0, stagger_lo = 0, stagger_hi = 0;  // workgroups [lo, hi) sleep `stagger` x 8128 cycles before they start (set by the launcher)
+    int generic_only = 0;       // 1: never the weight-stationary kernel (debug request "lg.gemm_generic": A/B and bit-identity tests)
 };
-void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s);
+void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s);   // tries launch_gemm_ws_f16x3 first
+bool launch_gemm_ws_f16x3(const GemmF16Args& a, hipStream_t s); // gemm_ws_f16.hip: K = 256, SH8 output, bias / rotary / scale only; false = not taken
 void launch_to_sh8(const float* in, void* out, long long elems, float scale, hipStream_t s);  // SH8(in * scale)
 void launch_from_sh8(const void* in, float* out, long long elems, hipStream_t s);          // hi + lo back to fp32
 

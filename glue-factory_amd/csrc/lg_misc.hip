@@ -227,7 +227,7 @@ __global__ __launch_bounds__(256) void assign_rows(const AssignArgs p) {
     }
     if (lane == 0) {
         p.row_best[r] = best;
-        p.row_arg[r] = arg;
+        p.row_arg[r] = arg < p.N ? arg : 0;  // (never an index outside the row: a row of NaNs leaves the sentinel, and the mutual check below indexes with this value)
         if (la) la[p.N] = p.lsn0[r];
     }
 }
@@ -268,7 +268,7 @@ __global__ __launch_bounds__(64 * ACW) void assign_cols(const AssignArgs p) {
         for (int k = 1; k < ACW; ++k)
             if (s_b[k][cl] > best || (s_b[k][cl] == best && s_a[k][cl] < arg)) { best = s_b[k][cl]; arg = s_a[k][cl]; }
         p.col_best[(long long)b * p.N + c] = best;
-        p.col_arg[(long long)b * p.N + c] = arg;
+        p.col_arg[(long long)b * p.N + c] = arg < p.M ? arg : 0;
     }
 }
 

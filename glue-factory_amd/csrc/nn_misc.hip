@@ -26,7 +26,7 @@ __device__ __forceinline__ int nn_decide(const NnArgs& p, const Top2& t) {
     bool ok = true;
     if (p.use_ratio) ok = ok && (d0 <= __fmul_rn(p.ratio2, d1));
     if (p.use_dist) ok = ok && (d0 <= p.dist2);
-    return ok ? t.i1 : -1;
+    return (ok && t.i1 != 0x7fffffff) ? t.i1 : -1;  // the sentinel survives a row of NaNs: no candidate, never an index
 }
 
 // one wave per row (b, i)

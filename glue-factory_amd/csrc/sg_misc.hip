@@ -314,7 +314,7 @@ __global__ __launch_bounds__(256) void sinkhorn_final_rows(const SinkArgs p, flo
     }
     if (lane == 0) {
         row_best[(long long)b * p.M + i] = best;
-        row_arg[(long long)b * p.M + i] = arg;
+        row_arg[(long long)b * p.M + i] = arg < p.N ? arg : 0;  // (never an index outside the row: a row of NaNs leaves the sentinel, and the mutual check below indexes with this value)
     }
 }
 
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void sinkhorn_final_cols(const SinkArgs p, flo
         for (int k = 1; k < 4; ++k)
             if (s_b[k][cl] > best || (s_b[k][cl] == best && s_a[k][cl] < arg)) { best = s_b[k][cl]; arg = s_a[k][cl]; }
         col_best[(long long)b * p.N + j] = best;
-        col_arg[(long long)b * p.N + j] = arg;
+        col_arg[(long long)b * p.N + j] = arg < p.M ? arg : 0;
     }
 }
 

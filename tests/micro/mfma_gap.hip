@@ -14,7 +14,7 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-enum { F_ADD = 0, F_EXP = 1, F_MIX = 2, F_ADD_DEP = 3, F_EXP_DEP = 4, F_SOFTMAX = 5, F_LDS = 6, F_CVT = 7 };
+enum { F_ADD = 0, F_EXP = 1, F_MIX = 2, F_ADD_DEP = 3, F_EXP_DEP = 4, F_SOFTMAX = 5, F_LDS = 6, F_CVT = 7, F_ACCREAD = 8, F_WAITCNT = 9, F_SNOP = 10, F_SALU = 11, F_CNDMASK = 12, F_DPP = 13, F_FMA = 14 };
 
 template <int ACC_AGPR, int KIND, int NF>
 __global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, float* sink, int iters) {
@@ -28,6 +28,9 @@ __global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, fl
     float r[8];
     for (int i = 0; i < 8; ++i) r[i] = 0.001f * (threadIdx.x + 1) + 0.37f * i;
     float c = 0.999f;
+    float spare[8];
+    for (int i = 0; i < 8; ++i) spare[i] = 0.5f + i;
+    int sreg = 0;
     const float* lp = lds + (threadIdx.x & 63) * 4;
     float4 ld = {0, 0, 0, 0};
     unsigned long long t0, t1;
@@ -35,7 +38,13 @@ __global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, fl
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int g = 0; g < 8; ++g) {
-            if (ACC_AGPR) {
+            if (ACC_AGPR == 3) {  // accumulators AND the A operand in the accumulator file (weights of gemm_ws_f16.hip, Q of attention_pw_f16.hip)
+                if (g & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc1) : "a"(a), "v"(b));
+                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc0) : "a"(a), "v"(b));
+            } else if (ACC_AGPR == 2) {  // VGPR accumulators, A operand in the accumulator file
+                if (g & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1) : "a"(a), "v"(b));
+                else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc0) : "a"(a), "v"(b));
+            } else if (ACC_AGPR) {
                 if (g & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc1) : "v"(a), "v"(b));
                 else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+a"(acc0) : "v"(a), "v"(b));
             } else {
@@ -57,6 +66,20 @@ __global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, fl
                     else if (k == 1 || k == 2) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
                     else if (k == 3) asm volatile("v_cvt_pkrtz_f16_f32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
                     else asm volatile("v_fma_mixlo_f16 %0, %0, -1.0, %1 op_sel:[0,0,0] op_sel_hi:[1,0,0]" : "+v"(r[i]) : "v"(c));
+                } else if (KIND == F_ACCREAD) {  // a VGPR <- AGPR copy of a register no MFMA of the loop touches (what hipcc emits when the vector pipe reads an accumulator)
+                    asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(r[i]) : "a"(spare[i]));
+                } else if (KIND == F_WAITCNT) {
+                    asm volatile("s_waitcnt lgkmcnt(7)" ::: "memory");
+                } else if (KIND == F_SNOP) {
+                    asm volatile("s_nop 0" ::: "memory");
+                } else if (KIND == F_SALU) {
+                    asm volatile("s_add_i32 %0, %0, 1" : "+s"(sreg));
+                } else if (KIND == F_CNDMASK) {
+                    asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(r[i]) : "v"(c) : );
+                } else if (KIND == F_DPP) {
+                    asm volatile("v_mov_b32_dpp %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[i]));
+                } else if (KIND == F_FMA) {
+                    asm volatile("v_fma_f32 %0, %0, %1, %1" : "+v"(r[i]) : "v"(c));
                 } else if (KIND == F_LDS) {
                     asm volatile("ds_read_b128 %0, %1" : "=v"(ld) : "v"((unsigned)(size_t)(__attribute__((address_space(3))) const float*)lp) : "memory");
                 }
@@ -65,7 +88,7 @@ __global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, fl
         if (KIND == F_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-    float s = ld.x + ld.y;
+    float s = ld.x + ld.y + (float)sreg;
     for (int i = 0; i < 8; ++i) s += r[i];
     for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
     if (s == 12345.678f) sink[threadIdx.x] = s;
@@ -99,6 +122,8 @@ static void row(const char* name) {
 }
 
 int main() {
+    printf("A operand in the accumulator file, no fillers / 4 v_add: VGPR acc %.1f / %.1f, AGPR acc %.1f / %.1f cycles per MFMA\n", run<2, F_ADD, 0>(4000), run<2, F_ADD, 4>(4000),
+           run<3, F_ADD, 0>(4000), run<3, F_ADD, 4>(4000));
     printf("shader cycles per MFMA gap (v_mfma_f32_32x32x16_f16, one wave per SIMD); fillers per gap: 0 2 3 4 5 6 8\n");
     row<F_ADD>("v_add_f32 (independent)");
     row<F_EXP>("v_exp_f32 (independent)");
@@ -108,6 +133,13 @@ int main() {
     row<F_ADD_DEP>("v_add_f32 (one dependent chain)");
     row<F_EXP_DEP>("v_exp_f32 (one dependent chain)");
     row<F_LDS>("ds_read_b128");
+    row<F_FMA>("v_fma_f32 (independent)");
+    row<F_CNDMASK>("v_cndmask_b32 (vcc)");
+    row<F_DPP>("v_mov_b32_dpp quad_perm");
+    row<F_ACCREAD>("v_accvgpr_read_b32");
+    row<F_WAITCNT>("s_waitcnt lgkmcnt(7) (nothing pending)");
+    row<F_SNOP>("s_nop 0");
+    row<F_SALU>("s_add_i32");
     hipError_t e = hipDeviceSynchronize();
     printf("status %s\n", hipGetErrorString(e));
     return e != hipSuccess;
