@@ -246,54 +246,57 @@ def cpu_baseline(matcher="lightglue", images="boat", budget_s=60.0, note=lambda 
 
 
 class PowerSampler:
-    """Board power and shader clock read from the amdgpu hwmon / sysfs files of the rank's device while the timed region runs (a thread
-    that only reads files: no child process, nothing on the GPU).  Evidence for the power-limited regime DESIGN.md describes: the board
-    sits near 90 % of its cap and the clock the chip holds is what gives.  Every field is None where the files are not readable."""
+    """Board power read from the amdgpu hwmon files while the timed region runs (a thread that only reads files: no child process,
+    nothing on the GPU).  Evidence for the power-limited regime DESIGN.md describes (round 4: the board sits near 90 % of its cap during
+    the step and the clock the chip holds is what gives).  A GPU box shows the hwmon entries of every GPU of its host; which entry
+    belongs to this rank's device is not derivable without a child process, so every entry is sampled and the one that draws the most over
+    the region -- the busy one -- is reported (at N > 1 every rank reports the maximum over the node's busy GPUs: read it as 'a busy
+    GPU', not 'this GPU').  Every field is None where the files are not readable."""
 
     def __init__(self, index):
         import glob
         import threading
 
-        self.samples, self.clocks, self._stop = [], [], threading.Event()
-        cards = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/power1_average")) or \
+        self._stop = threading.Event()
+        self.paths = sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/power1_average")) or \
             sorted(glob.glob("/sys/class/drm/card[0-9]*/device/hwmon/hwmon*/power1_input"))
-        self.path = cards[index] if index < len(cards) else None
-        self.cap = None
-        if self.path:
-            try:
-                self.cap = int(open(os.path.join(os.path.dirname(self.path), "power1_cap")).read()) / 1e6
-            except (OSError, ValueError):
-                pass
-            self.sclk = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(self.path))), "pp_dpm_sclk")
+        self.samples = {p: [] for p in self.paths}
         self._thread = threading.Thread(target=self._run, daemon=True)
 
     def _run(self):
         while not self._stop.is_set():
-            try:
-                self.samples.append(int(open(self.path).read()) / 1e6)
-                for line in open(self.sclk):
-                    if line.rstrip().endswith("*"):
-                        self.clocks.append(int("".join(ch for ch in line.split(":")[1] if ch.isdigit())))
-            except (OSError, ValueError, IndexError):
-                pass
+            for p in self.paths:
+                try:
+                    self.samples[p].append(int(open(p).read()) / 1e6)
+                except (OSError, ValueError):
+                    pass
             self._stop.wait(0.05)
 
     def __enter__(self):
-        if self.path:
+        if self.paths:
             self._thread.start()
         return self
 
     def __exit__(self, *a):
         self._stop.set()
-        if self.path:
+        if self.paths:
             self._thread.join(timeout=1.0)
 
     def summary(self):
-        if not self.samples:
+        best = None
+        for p, v in self.samples.items():
+            if v and (best is None or sorted(v)[len(v) // 2] > best[0]):
+                best = (sorted(v)[len(v) // 2], max(v), len(v), p)
+        if best is None:
             return None
-        s, c = sorted(self.samples), sorted(self.clocks)
-        return {"board_power_w_median": round(s[len(s) // 2], 1), "board_power_w_max": round(s[-1], 1), "power_cap_w": self.cap, "samples": len(s),
-                "sclk_mhz_median": (c[len(c) // 2] if c else None), "source": "amdgpu hwmon power1_average / pp_dpm_sclk, sampled every 50 ms over the timed region"}
+        cap = None
+        try:
+            cap = int(open(os.path.join(os.path.dirname(best[3]), "power1_cap")).read()) / 1e6
+        except (OSError, ValueError):
+            pass
+        return {"board_power_w_median": round(best[0], 1), "board_power_w_max": round(best[1], 1), "power_cap_w": cap, "samples": best[2],
+                "devices_sampled": len(self.paths),
+                "source": "amdgpu hwmon power1_average of the busiest visible GPU, sampled every 50 ms over the timed region"}
 
 
 def launch_ranks(args):

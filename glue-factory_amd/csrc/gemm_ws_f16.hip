@@ -144,14 +144,18 @@ __device__ __forceinline__ void ws_body(const WsArgs& p, u32x4* s_ring, u32x4* s
         const int o32 = off > 0x7fffff00ll ? 0x7fffff00 : (int)off;  // past 2 GiB: out of range anyway (M x 1 KiB < 2 GiB is checked by the launcher)
         dma_piece(rs_a, __builtin_amdgcn_readfirstlane(lds0 + slot * SLOT + (8 * wu + j) * 1024), vo[j] + o32);
     };
-    // fragment addresses (slot 0): token block tb, row 32 tb + i32, k-step u of the quarter: piece (2 u + h) * 2 [^ 1 for lo] ^ (row & 15)
-    unsigned fa[4];
+    // fragment addresses.  Row 32 tb + i32 of a slot, piece ((2 u + h) * 2 + hl) ^ (row & 15): the XOR only touches the piece bits, so
+    // the address is (slot + row i32 base) | X[u][hl] + tb * 8 KiB.  X is a lane constant (8 registers for the whole kernel), the slot base is
+    // added once per stage (8 vector adds: fcur for this stage's slot, fnext[hl] for k-step 0 of the next one) and the token block is the
+    // instruction's immediate offset -- no address arithmetic per read (it was an xor and an add for each of the 32 reads of a stage)
+    unsigned fx[4][2], fcur[4][2], fnext[2];
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) fa[tb] = lds0 + (32 * tb + i32) * 256 + ((((2 * 0 + h) * 2) ^ (i32 & 15)) << 4);
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int hl = 0; hl < 2; ++hl) fx[u][hl] = lds0 + i32 * 256 + (((((2 * u + h) * 2 + hl) ^ (i32 & 15))) << 4);
     f16x8 bh[2][4], bl[2][4];  // [k-step parity][token block]
-    auto read_b = [&](unsigned slot_off, int u, int tb, int hl) {
-        // piece index (2u + h) * 2 + hl, XOR (row & 15): relative to u = 0, hl = 0 the XOR of (4u + hl) commutes with the swizzle
-        const unsigned a = (fa[tb] ^ (unsigned)((4 * u + hl) << 4)) + slot_off;
+    auto read_b = [&](int u, int tb, int hl) {  // u = 0: k-step 0 of the NEXT stage (fnext), else k-step u of this stage (fcur)
+        const unsigned a = (u == 0 ? fnext[hl] : fcur[u][hl]) + tb * 8192;
         const f16x8 v = *(const lds_f16x8*)(size_t)a;
         if (hl) bl[u & 1][tb] = v;
         else bh[u & 1][tb] = v;
@@ -190,6 +194,12 @@ __device__ __forceinline__ void ws_body(const WsArgs& p, u32x4* s_ring, u32x4* s
         constexpr bool MMA = decltype(mmac)::value != 0;
         const unsigned off_cur = (unsigned)(sigma % RD) * SLOT, off_next = (unsigned)((sigma + 1) % RD) * SLOT;
         const int slot_free = sigma % RD;
+        if (MMA) {
+#pragma unroll
+            for (int u = 1; u < 4; ++u) { fcur[u][0] = fx[u][0] + off_cur; fcur[u][1] = fx[u][1] + off_cur; }
+            fnext[0] = fx[0][0] + off_next;
+            fnext[1] = fx[0][1] + off_next;
+        }
         // the packet requested in this stage belongs to stage sigma + RD: its token pieces, and the rotary pieces of the block whose epilogue
         // runs there -- block (sigma + RD) & 3 of the tile before tile (sigma + RD) >> 2 of this workgroup (none for its first tile)
         const int in = (sigma + RD) >> 2, qn = (sigma + RD) & 3;
@@ -199,7 +209,7 @@ __device__ __forceinline__ void ws_body(const WsArgs& p, u32x4* s_ring, u32x4* s
         auto run = [&](auto codec) {
             constexpr int code = decltype(codec)::value;
             constexpr int kind = code >> 8, a = (code >> 4) & 15, b = code & 15;
-            if constexpr (kind == gsch::BR) { if (MMA) read_b(a == 0 ? off_next : off_cur, a, b >> 1, b & 1); }
+            if constexpr (kind == gsch::BR) { if (MMA) read_b(a, b >> 1, b & 1); }
             else if constexpr (kind == gsch::DM) dma_stage(sigma + RD, slot_free, b);
             else if constexpr (kind == gsch::LE) {
                 const unsigned dst = __builtin_amdgcn_readfirstlane(enc0 + slot_free * 16384 + b * 1024);
@@ -280,8 +290,10 @@ __device__ __forceinline__ void ws_body(const WsArgs& p, u32x4* s_ring, u32x4* s
     }
     wait_vm<(ROT ? 12 : 8) * (RD - 1)>();
     __builtin_amdgcn_s_barrier();
+    fnext[0] = fx[0][0];
+    fnext[1] = fx[0][1];
 #pragma unroll
-    for (int tb = 0; tb < 4; ++tb) { read_b(0, 0, tb, 0); read_b(0, 0, tb, 1); }
+    for (int tb = 0; tb < 4; ++tb) { read_b(0, tb, 0); read_b(0, tb, 1); }
 
     // ---- tile loop: tile i on accumulator set i & 1, epilogue of tile i - 1 behind its MFMAs ---------------------------------------------
     auto tile = [&](auto curc, auto mmac, int i) {

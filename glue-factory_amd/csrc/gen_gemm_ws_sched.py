@@ -39,6 +39,10 @@ class Op:
     def __init__(self, kind, a, b, earliest=0, deadline=NG - 1):
         self.kind, self.a, self.b, self.earliest, self.deadline = kind, a, b, earliest, deadline
         self.deps, self.gap = [], None
+        # epilogue ops belong to the chain of their register pair: the scheduler finishes a pair before it starts the next one, so that
+        # few temporaries are alive at a time (the first table ran all 16 bias ops, then all 32 rotary products ...: 35 values per stage
+        # were parked in AGPRs and came back through v_accvgpr_read, 8 issue cycles each)
+        self.chain = {"BF": b >> 1, "SC": b >> 1}.get(kind, b if kind in ("RA", "RB", "RC", "RD", "RE", "RF", "HC", "LA", "LB") else 0)
 
     @property
     def code(self):
@@ -141,7 +145,7 @@ def schedule(ops, cap):
             ready = [o for o in todo if o.earliest <= g and all(d.gap is not None and d.gap <= g - dist for d, dist in o.deps)]
             if not ready:
                 break
-            ready.sort(key=lambda o: (o.deadline - g, KINDS.index(o.kind), o.a, o.b))
+            ready.sort(key=lambda o: (o.deadline - g if o.kind in ('BR', 'DM', 'LE', 'ST') else 99, o.chain, KINDS.index(o.kind), o.a, o.b))
             for o in ready:
                 if len(gaps[g]) < W and (cost[g] + COST[o.kind] <= cap or o.deadline <= g):
                     o.gap = g
