@@ -220,8 +220,14 @@ int mg_nn_forward(mg_handle h, const mg_nn_conf* conf, const float* desc0, const
 /* -- introspection ----------------------------------------------------------------------------
  * Copy a named internal buffer of the LAST forward into `dst` (device, fp32), for stage-wise
  * parity tests: "lg.enc" (tokens,64), "lg.self<i>" / "lg.layer<i>" (tokens,256) descriptors after
- * the self / cross block of layer i (both images, image-0 rows first).  Returns element count in
- * *count.  Only taps requested beforehand with mg_debug_request() are kept.                    */
+ * the self / cross block of layer i (both images, image-0 rows first), "lg.qkv0" (tokens,768) the raw
+ * rows of the first QKV projection (SH8 words in f16x3 mode).  Returns element count in *count.  Only
+ * taps requested beforehand with mg_debug_request() are kept.  A request may also name a KERNEL VARIANT
+ * kept for A/B timing and kernel-equivalence tests (no buffer behind it): "sp.conv_staged",
+ * "sp.conv1ab_staged", "sp.conv_dma32", "lg.unfused_ffn", "sp.logits", "lg.attn8" (the 8-wave attention
+ * kernel instead of attention_pw_f16.hip), "lg.gemm_generic" (the tiled GEMM instead of gemm_ws_f16.hip
+ * for the QKV projections), "lg.attn.exp<N>" (timing ablations of the attention kernel: WRONG results on
+ * purpose, for mg_test_attention only).                                                            */
 int mg_debug_request(mg_handle h, const char* tap);
 int mg_debug_read(mg_handle h, const char* tap, float* dst, size_t capacity, size_t* count, void* stream);
 
