@@ -28,6 +28,7 @@ SHORT = {
     "gemm_f16x3_kernel<true": "lg.gemm.sim",
     "attention_f16x3_kernel": "lg.attn",
     "attention_f16x3_pw_kernel": "lg.attn",
+    "gemm_ws_f16x3_kernel": "lg.gemm.qkv (weight-stationary)",
     "ffn_f16x3_kernel": "lg.ffn",
     "heads_f16x3_kernel": "sp.heads",
     "mfma_loop": "micro.mfma_peak (calibration: a register-only MFMA loop must read ~1.0)",

@@ -25,6 +25,7 @@ SHORT = {
     "gemm_f16x3_kernel<true": "lg.gemm.sim",
     "attention_f16x3_kernel": "lg.attn",
     "attention_f16x3_pw_kernel": "lg.attn",
+    "gemm_ws_f16x3_kernel": "lg.gemm.qkv (weight-stationary)",
     "nms_kernel": "sp.nms",
     "ln_gelu_kernel": "lg.ln_gelu",
     "ffn_f16x3_kernel": "lg.ffn",
