@@ -134,7 +134,7 @@ def schedule(ops, cap=CAP):
             if not ready:
                 break
             # most urgent first: slack to the deadline, then long chains first (SB before AD ...)
-            ready.sort(key=lambda o: (o.deadline - g, KINDS.index(o.kind)))
+            ready.sort(key=lambda o: (o.deadline - g, KINDS.index(o.kind), o.a, o.b))  # a total order: the table is reproducible
             placed = False
             for o in ready:
                 urgent = o.deadline <= g
