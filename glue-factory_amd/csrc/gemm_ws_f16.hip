@@ -89,7 +89,7 @@ struct WsArgs {
     int rotary_cols;
     float scale;
     int scale_cols;
-    int wg_per_xcd;     // persistent workgroups per XCD (a multiple of N / 128)
+    int grp_wgs[8];     // persistent workgroups per XCD of feature group g (N / 128 <= 8 groups): more for the groups with the longer epilogue
 };
 
 template <int ROT, int SCL>
@@ -324,7 +324,9 @@ __global__ __launch_bounds__(256) void gemm_ws_f16x3_kernel(const WsArgs p) {
     __shared__ __attribute__((aligned(1024))) u32x4 s_out[4 * 32 * 8];      // output staging: [wave][token of the block][8 pieces], swizzled
     const int ng = p.N / FEAT;
     const int xcd = blockIdx.x & 7, local = blockIdx.x >> 3;
-    const int grp = local % ng, lane_in_grp = local / ng, per_grp = p.wg_per_xcd / ng;
+    int grp = 0, lane_in_grp = local;  // the XCD's workgroups are dealt to the feature groups in blocks of grp_wgs[g]
+    while (grp + 1 < ng && lane_in_grp >= p.grp_wgs[grp]) lane_in_grp -= p.grp_wgs[grp++];
+    const int per_grp = p.grp_wgs[grp];
     const int fb0 = grp * FEAT;
     const bool rot = p.enc != nullptr && fb0 < p.rotary_cols, scl = fb0 < p.scale_cols;  // workgroup-uniform (the launcher checks the multiples)
     if (rot && scl) ws_body<1, 1>(p, s_ring, s_enc, s_out, grp, lane_in_grp, per_grp, xcd);
@@ -346,13 +348,34 @@ bool launch_gemm_ws_f16x3(const GemmF16Args& a, hipStream_t s) {
         int dev = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n_cu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n_cu < 8) n_cu = 256;
     }
-    int per_xcd = (n_cu / 8) / ng * ng;  // persistent workgroups per XCD: the largest multiple of the group count that fits
-    if (per_xcd < ng) return false;
-    const int ntiles = (a.M + TOK - 1) / TOK, tiles_per_xcd = (ntiles + 7) / 8;
-    while (per_xcd > ng && (per_xcd / ng - 1) >= tiles_per_xcd) per_xcd -= ng;  // no workgroups without tiles
+    if (ng > 8) return false;
+    // Workgroups per XCD and feature group.  A group's work per tile is its instruction count per stage (static counts of the four
+    // variants: no rotary / no scale 276, scale 290, rotary 357, rotary + scale 372): the q / k groups of the self projection get more
+    // workgroups than its v groups, so that every workgroup of a launch finishes at about the same time (largest-remainder split of the
+    // XCD's CUs; with equal shares the q workgroups ran 13 tiles of the longest kind while the v workgroups idled for a quarter of the launch)
+    const int ntiles = (a.M + TOK - 1) / TOK, tiles_per_xcd = (ntiles + 7) / 8, cus = n_cu / 8;
+    if (cus < ng) return false;
+    int cnt[8], cost[8], total = 0, used = 0;
+    for (int g = 0; g < ng; ++g) {
+        const bool rot = a.enc && g * FEAT < a.rotary_cols, scl = g * FEAT < a.scale_cols;
+        cost[g] = rot ? (scl ? 372 : 357) : (scl ? 290 : 276);
+        total += cost[g];
+    }
+    for (int g = 0; g < ng; ++g) { cnt[g] = cus * cost[g] / total; if (cnt[g] < 1) cnt[g] = 1; used += cnt[g]; }
+    while (used < cus) {  // hand the remaining CUs to the groups with the most work per workgroup
+        int best = 0;
+        for (int g = 1; g < ng; ++g) if ((long long)cost[g] * cnt[best] > (long long)cost[best] * cnt[g]) best = g;
+        ++cnt[best]; ++used;
+    }
+    while (used > cus) { int big = 0; for (int g = 1; g < ng; ++g) if (cnt[g] > cnt[big]) big = g; --cnt[big]; --used; }
+    for (int g = 0; g < ng; ++g) if (cnt[g] > tiles_per_xcd) { used -= cnt[g] - tiles_per_xcd; cnt[g] = tiles_per_xcd > 0 ? tiles_per_xcd : 1; }  // no workgroups without tiles
+    used = 0;
+    for (int g = 0; g < ng; ++g) used += cnt[g];
+    const int per_xcd = used;
     WsArgs w;
     w.A = a.A0; w.W = a.W; w.Npad = a.Npad; w.winv = a.winv; w.bias = a.bias; w.Cs = a.Cs; w.ldcs = a.ldcs; w.M = a.M; w.N = a.N;
-    w.enc = a.enc; w.rotary_cols = a.enc ? a.rotary_cols : 0; w.scale = a.scale; w.scale_cols = a.scale_cols; w.wg_per_xcd = per_xcd;
+    w.enc = a.enc; w.rotary_cols = a.enc ? a.rotary_cols : 0; w.scale = a.scale; w.scale_cols = a.scale_cols;
+    for (int g = 0; g < 8; ++g) w.grp_wgs[g] = g < ng ? cnt[g] : 0;
     hipLaunchKernelGGL(gemm_ws_f16x3_kernel, dim3(8 * per_xcd), dim3(256), 0, s, w);
     return true;
 }

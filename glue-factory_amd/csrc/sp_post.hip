@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 // tile per block with a 5r halo (the dependency radius of the three keep/suppress rounds).
 // max_pool2d pads with -inf, so everything outside the image is -inf / "not kept".
 constexpr int NMS_TILE = 32;
-constexpr int NMS_THREADS = 1024;  // 2 blocks/CU x 8 waves: the kernel is LDS-latency-bound, occupancy hides it
+constexpr int NMS_THREADS = 512;   // 4 blocks/CU (40 KB of LDS each) x 8 waves: the kernel is a chain of barriers with short tasks between them -- four independent chains per CU instead of two (round 4; 1024 threads: 2 blocks/CU)
 constexpr int COUNT_STRIDE = 32;  // ints between per-image candidate counters (one 128-B line each)
 
 // Separable (2R+1)^2 max-pool over a TxT LDS tile (row stride TP).  Each thread produces 4 adjacent
