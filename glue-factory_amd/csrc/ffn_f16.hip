@@ -57,14 +57,38 @@ template <int N>
 __device__ __forceinline__ void wait_vm() {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ void wait_lds() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// lgkmcnt(0) as the BUILTIN (0xC07F = vmcnt 63, expcnt 7, lgkmcnt 0 in the gfx9 encoding): hipcc's wait-count pass sees it and knows that
+// every fragment read issued before it has landed; an asm statement is opaque to that pass, which then protects the first MFMA behind
+// the barrier with a full lgkmcnt(0) of its own -- after the reads of the next k-step have been issued in front of that MFMA
+__device__ __forceinline__ void wait_lds() { __builtin_amdgcn_s_waitcnt(0xC07F); }
 // LDS accesses of this wave are complete, then the workgroup barrier (the raw s_barrier does not wait for them; DMA stays in flight)
 __device__ __forceinline__ void lds_barrier() {
     wait_lds();
     __builtin_amdgcn_s_barrier();
 }
 #define PIN() __builtin_amdgcn_sched_barrier(0)
-#ifndef MG_FFN_EXP  // timing ablations only (wrong results, finite values): bit 0/1 no DMA in the phase-3/1 loop, 2/5 no barriers, 3 no quarter writes
+// LDS-DMA as `buffer_load_dwordx4 ... offen lds` in inline asm (round 4): 1 KB per wave and request, lane l's 16 bytes land at m0 + 16 l.
+// (a) its issue is cheaper than the global_load_lds builtin's (tests/micro/mfma_gap.hip, profiles/r04_ad_mfma_gap_vmem.txt: one request every
+// fourth MFMA costs a lone wave 14 cycles instead of 28, every eighth 0 instead of 28: a 32-bit offset per lane instead of a 64-bit
+// address); (b) rows beyond the end of the buffer read as zeros by the range check -- no clamped row index; (c) hipcc does not see it,
+// and that is wanted: with the builtin in the instruction stream its wait-count pass has two kinds of LDS event pending and answers every
+// use of a fragment with lgkmcnt(0).  The vmcnt waits of this kernel were counted by hand already.
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void dma_piece(const i32x4 rsrc, unsigned lds_byte, int voffset, int soffset) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %3 offen lds" ::"s"(lds_byte), "v"(voffset), "s"(rsrc), "s"(soffset) : "memory");
+}
+__device__ __forceinline__ i32x4 make_rsrc(const void* base, long long bytes) {
+    const unsigned long long a = reinterpret_cast<unsigned long long>(base);
+    i32x4 r;
+    r[0] = __builtin_amdgcn_readfirstlane((int)(unsigned)a);
+    r[1] = __builtin_amdgcn_readfirstlane((int)(unsigned)(a >> 32) & 0xffff);  // stride 0, no swizzle
+    r[2] = __builtin_amdgcn_readfirstlane((int)(bytes > 0x7fffffffll ? 0x7fffffffll : bytes));
+    r[3] = 0x00020000;
+    return r;
+}
+#ifndef MG_FFN_EXP  // timing ablations only (wrong results, finite values): bit 0/1 no DMA in the phase-3/1 loop, 2/5 no barriers, 3 no quarter writes,
+                    // 6 (with the stamp instantiation) per-wave barrier waits of phase 3 instead of the phase stamps.  NOTE: without its barriers a
+                    // workgroup's stamps are wave 0's only -- the other waves may still be running (how round 2 overestimated the barrier cost)
 #define MG_FFN_EXP 0
 #endif
 constexpr int EXP = MG_FFN_EXP;
@@ -119,10 +143,12 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
     // 16-byte piece index of this lane's hi / lo fragment inside a tile whose first row is a multiple of 16
     const int lane_hi = swz(i32, 2 * h), lane_lo = swz(i32, 2 * h + 1);
 
-    const u32x4* A0 = reinterpret_cast<const u32x4*>(p.A0);
-    const u32x4* A1 = reinterpret_cast<const u32x4*>(p.A1);
-    const u32x4* W0 = reinterpret_cast<const u32x4*>(p.W0);
-    const u32x4* W3 = reinterpret_cast<const u32x4*>(p.W3);
+    auto lds_of = [](const u32x4* q) { return (unsigned)(size_t)(__attribute__((address_space(3))) const char*)reinterpret_cast<const char*>(q); };
+    const long long tok_bytes = (long long)min(TMF, p.T - m0) * 1024;  // this workgroup's rows of the (T, 256) SH8 operands; rows beyond read as zeros
+    const i32x4 rs_a0 = make_rsrc(reinterpret_cast<const char*>(p.A0) + (long long)m0 * 1024, tok_bytes);
+    const i32x4 rs_a1 = make_rsrc(reinterpret_cast<const char*>(p.A1) + (long long)m0 * 1024, tok_bytes);
+    const i32x4 rs_w0 = make_rsrc(p.W0, (long long)(HID / 16) * W1_STAGE * 16);
+    const i32x4 rs_w3 = make_rsrc(p.W3, (long long)(HID / 16) * W3_STAGE * 16);
 
     // per-feature parameters -> LDS by DMA as well (a plain load here would make hipcc drain the whole DMA prologue at its use)
     {
@@ -133,7 +159,7 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
         else if (piece < 4) src = ACT == ACT_LN_GELU ? p.gamma + (piece - 2) * 256 : nullptr;
         else if (piece < 6) src = ACT == ACT_LN_GELU ? p.beta + (piece - 4) * 256 : nullptr;
         else if (piece == 6) src = p.b3;
-        if (src) __builtin_amdgcn_global_load_lds(reinterpret_cast<const u32x4*>(src) + lane, dst + piece * 64, 16, 0, 0);
+        if (src) dma_piece(make_rsrc(src, 1024), __builtin_amdgcn_readfirstlane(lds_of(dst + piece * 64)), lane * 16, 0);
     }
 
     // ---- phase 1: H = W0f . A^T ----------------------------------------------------------------------------------
@@ -141,23 +167,19 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
     u32x4* const s_w1 = s_ring + RS * TOK_STAGE;
     // DMA sources of this lane: token piece wu (rows 16 wu ..), weight pieces 4 wu + j; the LDS image is linear, the XOR swizzle
     // is applied to the source piece
-    long long tok_off;
-    int w_off[4];
+    int tok_vo, w_vo;  // byte offsets of this lane's 16 bytes: token piece wu (row-in-tile x 1024 + swizzled quarter), weight pieces 4 wu + j (+ 1024 j)
     {
         const int slot = wu * 64 + lane, row = slot >> 2, q = (slot & 3) ^ ((row >> 2) & 3);
-        tok_off = (long long)min(m0 + row, p.T - 1) * 64 + q;
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int sl = (wu * 4 + j) * 64 + lane, r = sl >> 2;
-            w_off[j] = r * 4 + ((sl & 3) ^ ((r >> 2) & 3));
-        }
+        tok_vo = row * 1024 + q * 16;
+        const int sl = (wu * 4) * 64 + lane, r = sl >> 2;
+        w_vo = (r * 4 + ((sl & 3) ^ ((r >> 2) & 3))) * 16;  // piece 4 wu + j is 16 rows further: same swizzle term, + 1024 j bytes
     }
+    const unsigned lds_tok = lds_of(s_tok) + wu * 1024, lds_w1 = lds_of(s_w1) + wu * 4096;
     auto dma_tok = [&](int kt) {
-        const u32x4* src = (kt < 16 ? A0 : A1) + tok_off + (kt & 15) * 4;
-        __builtin_amdgcn_global_load_lds(src, s_tok + (kt % RS) * TOK_STAGE + wu * 64, 16, 0, 0);
+        dma_piece(kt < 16 ? rs_a0 : rs_a1, __builtin_amdgcn_readfirstlane(lds_tok + (kt % RS) * (TOK_STAGE * 16)), tok_vo, (kt & 15) * 64);
     };
     auto dma_w1 = [&](int kt, int j) {
-        __builtin_amdgcn_global_load_lds(W0 + (long long)kt * W1_STAGE + w_off[j], s_w1 + (kt % RS) * W1_STAGE + (wu * 4 + j) * 64, 16, 0, 0);
+        dma_piece(rs_w0, __builtin_amdgcn_readfirstlane(lds_w1 + (kt % RS) * (W1_STAGE * 16) + j * 1024), w_vo, kt * (W1_STAGE * 16) + j * 1024);
     };
 
     f32x16 acc[2][4];  // [hidden tile of this wave][token tile]
@@ -232,10 +254,14 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
     u32x4* const s_h = s_ring;                      // H' ring
     u32x4* const s_w3 = s_ring + HR * TOK_STAGE;
     constexpr int NK3 = HID / 16;
-    auto dma_w3 = [&](int kt, int j) {  // 256 rows x 64 B = 16 pieces: two per wave (rows of pieces 2 wu + j: the first 128 rows of w_off's map)
-        const int sl = (wu * 2 + j) * 64 + lane, r = sl >> 2;
-        const int off = r * 4 + ((sl & 3) ^ ((r >> 2) & 3));
-        __builtin_amdgcn_global_load_lds(W3 + (long long)kt * W3_STAGE + off, s_w3 + (kt % RS3) * W3_STAGE + (wu * 2 + j) * 64, 16, 0, 0);
+    int w3_vo;  // pieces 2 wu + j of a 16-piece stage (256 rows x 64 B)
+    {
+        const int sl = (wu * 2) * 64 + lane, r = sl >> 2;
+        w3_vo = (r * 4 + ((sl & 3) ^ ((r >> 2) & 3))) * 16;
+    }
+    const unsigned lds_w3 = lds_of(s_w3) + wu * 2048;
+    auto dma_w3 = [&](int kt, int j) {
+        dma_piece(rs_w3, __builtin_amdgcn_readfirstlane(lds_w3 + (kt % RS3) * (W3_STAGE * 16) + j * 1024), w3_vo, kt * (W3_STAGE * 16) + j * 1024);
     };
 #pragma unroll
     for (int s0 = 0; s0 < 3; ++s0) {
@@ -394,8 +420,6 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
     // a compile-time fact.  12 MFMAs per k-step, MFMA-first, four accumulators in rotation; every later MFMA carries one filler.
     auto kstep = [&](int S, int kt, int j, bool second) {
         const int rd_kt = kt + 1;                    // fragments to fetch under these MFMAs (into the other register set)
-        const int wr_kt = second ? 2 * j + 8 : 2 * j + 7;  // hidden k-step to publish (pre-loop wrote 0..7)
-        const bool writer = wr_kt >= HR && wr_kt < NK3 && wu == (wr_kt & 7) && !(EXP & 8);
         int slot_i = 0;
         auto filler = [&]() {
             const int f = slot_i++ - 1;
@@ -404,10 +428,7 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
                 if (2 * j + 3 + f < NK3 && !(EXP & 1)) { dma_w3(2 * j + 3 + f, 0); dma_w3(2 * j + 3 + f, 1); }
             }
             const int r = second ? f : f - 2;
-            if (r >= 0 && r < 8) {
-                if (rd_kt < NK3) read3(1 - S, rd_kt, r);
-                if (writer) write_piece(wr_kt >> 3, wr_kt % HR, r);
-            }
+            if (r >= 0 && r < 8 && rd_kt < NK3) read3(1 - S, rd_kt, r);
             PIN();
         };
         o[0][0] = mfma16(ch[S][0], dh[S][0], o[0][0]); filler();
@@ -423,10 +444,27 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
         o[1][0] = mfma16(cl[S][1], dh[S][0], o[1][0]); filler();
         o[1][1] = mfma16(cl[S][1], dh[S][1], o[1][1]); filler();
     };
+    // the hidden slabs of k-steps 2j+7, 2j+8 (pre-loop wrote 0..7), by their owner waves, AFTER the interval's MFMAs (round 4): behind a
+    // branch hipcc cannot count LDS operations, and with the stores among the fillers every k-step began with a full lgkmcnt(0)
+    auto publish = [&](int j) {
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int wr_kt = 2 * j + 7 + k;
+            if (wr_kt >= HR && wr_kt < NK3 && !(EXP & 8) && wu == (wr_kt & 7)) {
+#pragma unroll
+                for (int r = 0; r < 8; ++r) write_piece(wr_kt >> 3, wr_kt % HR, r);
+            }
+        }
+    };
+    unsigned long long t_wait = 0, t_vm = 0;  // STAMP only: cycles wave 0 spends in the vmcnt wait + LDS wait + barrier of the 16 intervals / in the vmcnt wait alone
 #pragma unroll
     for (int j = 0; j < NK3 / 2; ++j) {
+        unsigned long long t_a = 0;
+        if constexpr (STAMP) t_a = __builtin_amdgcn_s_memtime();
         wait_vm<0>();  // stages 2j+1, 2j+2 (and, once, the residual rows) -- everything this wave has in flight
+        if constexpr (STAMP) t_vm += __builtin_amdgcn_s_memtime() - t_a;
         if (!(EXP & 4)) lds_barrier();
+        if constexpr (STAMP) t_wait += __builtin_amdgcn_s_memtime() - t_a;
         PIN();
         if (j == NK3 / 2 - 3) {  // the hidden block's registers are free from here on: fetch the residual rows under the last MFMAs
 #pragma unroll
@@ -445,9 +483,13 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
         }
         kstep(0, 2 * j, j, false);
         kstep(1, 2 * j + 1, j, true);
+        publish(j);
     }
 
     stamp(4);
+    if constexpr (STAMP) {
+        if (t == 0) { p.stamps[blockIdx.x * 8 + 6] = (float)t_wait; p.stamps[blockIdx.x * 8 + 7] = (float)t_vm; }
+    }
     // ---- epilogue: + b3, + residual, fp32 row and SH8 copy --------------------------------------------------------------
     asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");  // MFMA results -> inline-asm permlane reads
 #pragma unroll
@@ -501,6 +543,10 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
     if constexpr (STAMP) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         stamp(5);
+        if (EXP & 64) {  // diagnostic variant: slot w = what wave w spent in the waits + barriers of phase 3 (replaces the phase stamps)
+            __syncthreads();
+            if (lane == 0) p.stamps[blockIdx.x * 8 + wu] = (float)t_wait;
+        }
     }
 }
 

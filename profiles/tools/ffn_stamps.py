@@ -28,13 +28,23 @@ eng = m.engine(dev)
 for _ in range(20):  # warm clocks
     m(d)
 eng.debug_request("ffn.stamps")
+for req in [a for a in sys.argv[1:] if not a.startswith('--')]:  # e.g. lg.ffn8 = the eight-wave kernel
+    eng.debug_request(req)
 for _ in range(3):
     m(d)
 torch.cuda.synchronize()
 n = (2 * B * K + 127) // 128
 st = eng.debug_read("ffn.stamps", n * 8).cpu().reshape(n, 8)
+if "--per-wave" in sys.argv:  # library built with -DMG_FFN_EXP=64
+    print("phase 3 waits + barriers per wave (median over workgroups): " + ", ".join(f"{v:.0f}" for v in st.median(0).values.tolist()))
+    sys.exit(0)
 names = ["start", "phase 1 (ffn.0 GEMM)", "phase 2 (bias, LayerNorm, GELU)", "split + first quarter", "phase 3 (ffn.3 GEMM)", "epilogue"]
 med = st.median(0).values
 print(f"{n} workgroups; median cycles since workgroup start: " + ", ".join(f"{v:.0f}" for v in med[:6].tolist()))
 for i in range(1, 6):
     print(f"  {names[i]:36s} {float(med[i] - med[i - 1]):9.0f} cycles ({float((med[i] - med[i - 1]) / med[5]) * 100:5.1f} %)")
+print(f"  phase 3, wave 0: vmcnt wait + LDS wait + barrier of the 16 intervals {float(med[6]):.0f} cycles, of which the vmcnt wait {float(med[7]):.0f} (eight-wave kernel only)")
+half = n // 2
+for nm, sl in (("workgroups 0..%d (first round of the grid)" % (half - 1), slice(0, half)), ("workgroups %d..%d (second round)" % (half, n - 1), slice(half, n))):
+    m2 = st[sl].median(0).values
+    print(f"  {nm}: " + ", ".join(f"{float(m2[i] - m2[i - 1]):.0f}" for i in range(1, 6)))

@@ -14,11 +14,11 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
-enum { F_ADD = 0, F_EXP = 1, F_MIX = 2, F_ADD_DEP = 3, F_EXP_DEP = 4, F_SOFTMAX = 5, F_LDS = 6, F_CVT = 7, F_ACCREAD = 8, F_WAITCNT = 9, F_SNOP = 10, F_SALU = 11, F_CNDMASK = 12, F_DPP = 13, F_FMA = 14 };
+enum { F_ADD = 0, F_EXP = 1, F_MIX = 2, F_ADD_DEP = 3, F_EXP_DEP = 4, F_SOFTMAX = 5, F_LDS = 6, F_CVT = 7, F_ACCREAD = 8, F_WAITCNT = 9, F_SNOP = 10, F_SALU = 11, F_CNDMASK = 12, F_DPP = 13, F_FMA = 14, F_DMA = 15, F_GLOAD = 16, F_DMA_BUF = 17 };
 
 template <int ACC_AGPR, int KIND, int NF>
-__global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, float* sink, int iters) {
-    __shared__ float lds[4096];
+__global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, float* sink, int iters, const float* src = nullptr) {
+    __shared__ float lds[4096 + 4 * 4 * 256];
     for (int i = threadIdx.x; i < 4096; i += 256) lds[i] = i * 0.001f;
     __syncthreads();
     f32x16 acc0, acc1;
@@ -33,6 +33,17 @@ __global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, fl
     int sreg = 0;
     const float* lp = lds + (threadIdx.x & 63) * 4;
     float4 ld = {0, 0, 0, 0};
+    float4 gl[4] = {};
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t rsrc;
+    {
+        const unsigned long long a = (unsigned long long)src;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)a);
+        rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32) & 0xffff);
+        rsrc[2] = 0x7fffffffu;
+        rsrc[3] = 0x00020000u;
+    }
+    const unsigned m0v = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + 4096 + (threadIdx.x >> 6) * 1024));
     unsigned long long t0, t1;
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
     for (int it = 0; it < iters; ++it) {
@@ -51,8 +62,18 @@ __global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, fl
                 if (g & 1) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc1) : "v"(a), "v"(b));
                 else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc0) : "v"(a), "v"(b));
             }
+            if ((KIND == F_DMA || KIND == F_GLOAD || KIND == F_DMA_BUF) && NF > 0 && g % NF == 0) {  // VMEM kinds: ONE request every NF-th gap (L2-resident source)
+                const float* gp = src + ((blockIdx.x & 15) * 8 + g) * 256 + (threadIdx.x & 63) * 4;
+                if (KIND == F_DMA) {
+                    __builtin_amdgcn_global_load_lds(reinterpret_cast<const uint4*>(gp), (__attribute__((address_space(3))) void*)(lds + 4096 + (threadIdx.x >> 6) * 1024 + (g & 3) * 256), 16, 0, 0);
+                } else if (KIND == F_GLOAD) {
+                    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(gl[g & 3]) : "v"(gp) : "memory");
+                } else {
+                    asm volatile("s_mov_b32 m0, %2\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"((unsigned)(((blockIdx.x & 15) * 8 + g) * 1024 + (threadIdx.x & 63) * 16)), "s"(rsrc), "s"(m0v + (g & 3) * 1024) : "memory");
+                }
+            }
 #pragma unroll
-            for (int f = 0; f < NF; ++f) {
+            for (int f = 0; f < ((KIND == F_DMA || KIND == F_GLOAD || KIND == F_DMA_BUF) ? 0 : NF); ++f) {
                 const int i = (g * NF + f) & 7;
                 if (KIND == F_ADD) asm volatile("v_add_f32 %0, %0, %1" : "+v"(r[i]) : "v"(c));
                 else if (KIND == F_EXP) asm volatile("v_exp_f32 %0, %0" : "+v"(r[i]));
@@ -86,9 +107,10 @@ __global__ __launch_bounds__(256) void gap_kernel(unsigned long long* cycles, fl
             }
         }
         if (KIND == F_LDS) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (KIND == F_DMA || KIND == F_GLOAD || KIND == F_DMA_BUF) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
-    float s = ld.x + ld.y + (float)sreg;
+    float s = ld.x + ld.y + (float)sreg + gl[0].x + gl[1].y + gl[2].z + gl[3].w + lds[4096 + threadIdx.x];
     for (int i = 0; i < 8; ++i) s += r[i];
     for (int i = 0; i < 16; ++i) s += acc0[i] + acc1[i];
     if (s == 12345.678f) sink[threadIdx.x] = s;
@@ -101,8 +123,10 @@ static double run(int iters) {
     float* sink;
     hipMalloc(&d, 256 * 4 * 8);
     hipMalloc(&sink, 4096);
-    hipLaunchKernelGGL((gap_kernel<ACC_AGPR, KIND, NF>), dim3(256), dim3(256), 0, 0, d, sink, iters);
-    hipLaunchKernelGGL((gap_kernel<ACC_AGPR, KIND, NF>), dim3(256), dim3(256), 0, 0, d, sink, iters);
+    static float* src = nullptr;
+    if (!src) { hipMalloc(&src, 16 * 8 * 1024 + 4096); hipMemset(src, 0, 16 * 8 * 1024 + 4096); }
+    hipLaunchKernelGGL((gap_kernel<ACC_AGPR, KIND, NF>), dim3(256), dim3(256), 0, 0, d, sink, iters, src);
+    hipLaunchKernelGGL((gap_kernel<ACC_AGPR, KIND, NF>), dim3(256), dim3(256), 0, 0, d, sink, iters, src);
     std::vector<unsigned long long> h(1024);
     hipMemcpy(h.data(), d, 1024 * 8, hipMemcpyDeviceToHost);
     hipFree(d);
@@ -140,6 +164,10 @@ int main() {
     row<F_WAITCNT>("s_waitcnt lgkmcnt(7) (nothing pending)");
     row<F_SNOP>("s_nop 0");
     row<F_SALU>("s_add_i32");
+    printf("VMEM requests of 1 KB per wave (16 B per lane, L2-resident source), one every N-th gap; cycles per MFMA gap for N = none 1 2 4 8\n");
+    printf("%-34s AGPR acc: %5.1f %5.1f %5.1f %5.1f %5.1f\n", "global_load_lds_dwordx4 (LDS-DMA)", run<1, F_DMA, 0>(2000), run<1, F_DMA, 1>(2000), run<1, F_DMA, 2>(2000), run<1, F_DMA, 4>(2000), run<1, F_DMA, 8>(2000));
+    printf("%-34s AGPR acc: %5.1f %5.1f %5.1f %5.1f %5.1f\n", "buffer_load_dwordx4 ... lds", run<1, F_DMA_BUF, 0>(2000), run<1, F_DMA_BUF, 1>(2000), run<1, F_DMA_BUF, 2>(2000), run<1, F_DMA_BUF, 4>(2000), run<1, F_DMA_BUF, 8>(2000));
+    printf("%-34s AGPR acc: %5.1f %5.1f %5.1f %5.1f %5.1f\n", "global_load_dwordx4 (registers)", run<1, F_GLOAD, 0>(2000), run<1, F_GLOAD, 1>(2000), run<1, F_GLOAD, 2>(2000), run<1, F_GLOAD, 4>(2000), run<1, F_GLOAD, 8>(2000));
     hipError_t e = hipDeviceSynchronize();
     printf("status %s\n", hipGetErrorString(e));
     return e != hipSuccess;
