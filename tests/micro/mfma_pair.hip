@@ -38,6 +38,81 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel(unsigned long long* cy
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * WAVES + (threadIdx.x >> 6)] = t1 - t0;
 }
 
+// Ping-pong: waves 0-3 (one per SIMD) run a BURST of MFMAs while waves 4-7 (their SIMD partners) issue NREAD ds_read_b128, NWRITE ds_write_b128
+// and NDMA LDS-DMA requests and wait for them; a barrier; roles swap; a barrier.  Cycles per SLOT (one burst of a SIMD): BURST x 32 = the pipe never idles.
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO>
+__global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycles, float* sink, int iters, const float* src) {
+    __shared__ float lds[8 * 4096];
+    for (int i = threadIdx.x; i < 8 * 4096; i += 512) lds[i] = i * 0.001f;
+    f32x16 acc[4];
+    for (int a = 0; a < 4; ++a)
+        for (int r = 0; r < 16; ++r) acc[a][r] = 0.f;
+    f16x8 a, b;
+    for (int j = 0; j < 8; ++j) { a[j] = (_Float16)(0.01f * ((threadIdx.x * 7 + j * 13) % 97)); b[j] = (_Float16)(0.02f * ((threadIdx.x * 11 + j * 5) % 89)); }
+    const int wave = threadIdx.x >> 6, grp = __builtin_amdgcn_readfirstlane(wave >> 2);
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t rsrc;
+    {
+        const unsigned long long ad = (unsigned long long)src;
+        rsrc[0] = __builtin_amdgcn_readfirstlane((unsigned)ad);
+        rsrc[1] = __builtin_amdgcn_readfirstlane((unsigned)(ad >> 32) & 0xffff);
+        rsrc[2] = 0x7fffffffu;
+        rsrc[3] = 0x00020000u;
+    }
+    const unsigned lbase = (unsigned)(size_t)(__attribute__((address_space(3))) float*)(lds + wave * 4096);
+    const unsigned m0v = __builtin_amdgcn_readfirstlane(lbase + 8192);
+    const unsigned laddr = lbase + (threadIdx.x & 63) * 16;
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    v4f ld[8];
+    for (int i = 0; i < 8; ++i) ld[i] = v4f{0, 0, 0, 0};
+    __syncthreads();
+    unsigned long long t0, t1;
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t0)::"memory");
+    auto burst = [&]() {
+        if (SETPRIO) asm volatile("s_setprio 2" ::: "memory");
+#pragma unroll
+        for (int g = 0; g < BURST; ++g) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a), "v"(b));
+        if (SETPRIO) asm volatile("s_setprio 0" ::: "memory");
+    };
+    auto mem = [&](int it) {
+#pragma unroll
+        for (int i = 0; i < NDMA; ++i)
+            asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"((unsigned)(((blockIdx.x & 15) * 8 + ((it + i) & 7)) * 1024 + (threadIdx.x & 63) * 16)), "s"(rsrc), "s"(m0v + i * 1024) : "memory");
+#pragma unroll
+        for (int i = 0; i < NREAD; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld[i & 7]) : "v"(laddr), "n"((i & 7) * 1024) : "memory");
+#pragma unroll
+        for (int i = 0; i < NWRITE; ++i) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(laddr), "v"(ld[i & 7]), "n"(8192 + 4096) : "memory");
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    };
+    for (int it = 0; it < iters; ++it) {
+        if (grp == 0) { burst(); __builtin_amdgcn_s_barrier(); mem(it); __builtin_amdgcn_s_barrier(); }
+        else { mem(it); __builtin_amdgcn_s_barrier(); burst(); __builtin_amdgcn_s_barrier(); }
+    }
+    asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
+    float s = 0.f;
+    for (int q = 0; q < 4; ++q)
+        for (int i = 0; i < 16; ++i) s += acc[q][i];
+    for (int i = 0; i < 8; ++i) s += ld[i].x + ld[i].w;
+    if (s == 12345.678f) sink[threadIdx.x] = s;
+    if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
+}
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO = 0>
+static double run_pp(int iters) {
+    unsigned long long* d;
+    float* sink;
+    static float* src = nullptr;
+    if (!src) { hipMalloc(&src, 16 * 8 * 1024 + 4096); hipMemset(src, 0, 16 * 8 * 1024 + 4096); }
+    hipMalloc(&d, 256 * 8 * 8);
+    hipMalloc(&sink, 4096);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((pingpong_kernel<BURST, NREAD, NWRITE, NDMA, SETPRIO>), dim3(256), dim3(512), 0, 0, d, sink, iters, src);
+    std::vector<unsigned long long> h(256 * 8);
+    hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
+    hipFree(d);
+    hipFree(sink);
+    std::sort(h.begin(), h.end());
+    return (double)h[h.size() / 2] / (2.0 * iters);  // cycles per slot
+}
+
 template <int NACC, int WAVES, int BURST, int BARRIER, int SETPRIO = 0>
 static double run(int iters) {
     unsigned long long* d;
@@ -63,6 +138,15 @@ int main() {
     printf("two waves per SIMD, 4 acc: %5.1f %5.1f %5.1f | %5.1f\n", run<4, 8, 12, 1>(it), run<4, 8, 24, 1>(it), run<4, 8, 48, 1>(it), run<4, 8, 24, 0>(it));
     printf("two waves per SIMD, 8 acc: %5.1f %5.1f %5.1f | %5.1f\n", run<8, 8, 12, 1>(it), run<8, 8, 24, 1>(it), run<8, 8, 48, 1>(it), run<8, 8, 24, 0>(it));
     printf("two waves per SIMD, 4 acc, s_setprio 1 around the burst: %5.1f %5.1f %5.1f | %5.1f\n", run<4, 8, 12, 1, 1>(it), run<4, 8, 24, 1, 1>(it), run<4, 8, 48, 1, 1>(it), run<4, 8, 24, 0, 1>(it));
+    printf("ping-pong (waves 0-3 multiply while waves 4-7 load, then swap; a barrier per slot): cycles per slot, ideal = 32 x burst\n");
+    printf("  burst 12 / 24 / 48, partner idle:               %6.1f %6.1f %6.1f (ideal 384 768 1536)\n", run_pp<12, 0, 0, 0>(it), run_pp<24, 0, 0, 0>(it), run_pp<48, 0, 0, 0>(it));
+    printf("  burst 12, partner 4 reads / 2 reads:            %6.1f %6.1f\n", run_pp<12, 4, 0, 0>(it), run_pp<12, 2, 0, 0>(it));
+    printf("  burst 12, partner 8 reads:                      %6.1f (ideal 384)\n", run_pp<12, 8, 0, 0>(it));
+    printf("  burst 12, partner 8 reads + 2 DMA:              %6.1f\n", run_pp<12, 8, 0, 2>(it));
+    printf("  burst 12, partner 8 reads + 8 writes + 4 DMA:   %6.1f\n", run_pp<12, 8, 8, 4>(it));
+    printf("  burst 12, same, s_setprio 2 around the burst:   %6.1f\n", run_pp<12, 8, 8, 4, 1>(it));
+    printf("  burst 24, partner 12 reads + 5 DMA:             %6.1f (ideal 768)\n", run_pp<24, 12, 0, 5>(it));
+    printf("  burst 24, partner 16 reads + 8 writes + 4 DMA:  %6.1f\n", run_pp<24, 16, 8, 4>(it));
     hipError_t e = hipDeviceSynchronize();
     printf("status %s\n", hipGetErrorString(e));
     return e != hipSuccess;
