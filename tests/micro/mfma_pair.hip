@@ -40,9 +40,9 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel(unsigned long long* cy
 
 // Ping-pong: waves 0-3 (one per SIMD) run a BURST of MFMAs while waves 4-7 (their SIMD partners) issue NREAD ds_read_b128, NWRITE ds_write_b128
 // and NDMA LDS-DMA requests and wait for them; a barrier; roles swap; a barrier.  Cycles per SLOT (one burst of a SIMD): BURST x 32 = the pipe never idles.
-template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO>
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO, int BIGLDS = 0>
 __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycles, float* sink, int iters, const float* src) {
-    __shared__ float lds[8 * 4096];
+    __shared__ float lds[BIGLDS ? 36 * 1024 : 8 * 4096];  // BIGLDS: 144 KB, one workgroup per CU by LDS as in ffn_f16.hip
     for (int i = threadIdx.x; i < 8 * 4096; i += 512) lds[i] = i * 0.001f;
     f32x16 acc[4];
     for (int a = 0; a < 4; ++a)
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycle
     if (s == 12345.678f) sink[threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
-template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO = 0>
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO = 0, int BIGLDS = 0>
 static double run_pp(int iters) {
     unsigned long long* d;
     float* sink;
@@ -104,7 +104,7 @@ static double run_pp(int iters) {
     if (!src) { hipMalloc(&src, 16 * 8 * 1024 + 4096); hipMemset(src, 0, 16 * 8 * 1024 + 4096); }
     hipMalloc(&d, 256 * 8 * 8);
     hipMalloc(&sink, 4096);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((pingpong_kernel<BURST, NREAD, NWRITE, NDMA, SETPRIO>), dim3(256), dim3(512), 0, 0, d, sink, iters, src);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((pingpong_kernel<BURST, NREAD, NWRITE, NDMA, SETPRIO, BIGLDS>), dim3(256), dim3(512), 0, 0, d, sink, iters, src);
     std::vector<unsigned long long> h(256 * 8);
     hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
     hipFree(d);
@@ -147,6 +147,7 @@ int main() {
     printf("  burst 12, same, s_setprio 2 around the burst:   %6.1f\n", run_pp<12, 8, 8, 4, 1>(it));
     printf("  burst 24, partner 12 reads + 5 DMA:             %6.1f (ideal 768)\n", run_pp<24, 12, 0, 5>(it));
     printf("  burst 24, partner 16 reads + 8 writes + 4 DMA:  %6.1f\n", run_pp<24, 16, 8, 4>(it));
+    printf("  burst 24, partner 16 reads (+ 8 writes), no DMA:  %6.1f %6.1f; with a 144 KB LDS allocation: %6.1f %6.1f\n", run_pp<24, 16, 0, 0>(it), run_pp<24, 16, 8, 0>(it), run_pp<24, 16, 0, 0, 0, 1>(it), run_pp<24, 16, 8, 0, 0, 1>(it));
     hipError_t e = hipDeviceSynchronize();
     printf("status %s\n", hipGetErrorString(e));
     return e != hipSuccess;
