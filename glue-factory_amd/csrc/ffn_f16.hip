@@ -512,31 +512,37 @@ __global__ __launch_bounds__(FT, 2) void ffn_f16x3_kernel(const FfnF16Args p) {
                 w[j] = fma_winv_asm(w[j], p.winv3, bv.x) + resid[ft][tt][j]; w[j + 1] = fma_winv_asm(w[j + 1], p.winv3, bv.y) + resid[ft][tt][j + 1];
                 w[j + 2] = fma_winv_asm(w[j + 2], p.winv3, bv.z) + resid[ft][tt][j + 2]; w[j + 3] = fma_winv_asm(w[j + 3], p.winv3, bv.w) + resid[ft][tt][j + 3];
             }
-            const int ql = i32 & 3;
-            const int tq = m0 + wt3 * 64 + tt * 32 + (i32 & ~3);  // first token of this lane's quad
-            {
-                u32x4 q0 = __builtin_bit_cast(u32x4, f32x4{w[0], w[1], w[2], w[3]}), q1 = __builtin_bit_cast(u32x4, f32x4{w[4], w[5], w[6], w[7]});
-                u32x4 q2 = __builtin_bit_cast(u32x4, f32x4{w[8], w[9], w[10], w[11]}), q3 = __builtin_bit_cast(u32x4, f32x4{w[12], w[13], w[14], w[15]});
-                quad_transpose(q0, q1, q2, q3, ql);
+            // The lane holds 64 contiguous bytes (4 pieces) of its token's row, twice (fp32 and SH8).  They go through a 4 KB LDS image
+            // private to the wave -- [token 32][piece 8], piece XOR (token & 7) -- and come back so that eight consecutive lanes hold the
+            // 128 contiguous bytes of one token: every store instruction writes eight full lines.  (Until round 4 a 4 x 4 quad transpose
+            // in registers did this: ~100 VALU instructions per transpose, 1 175 of them per wave in an epilogue no MFMA hides; the image
+            // costs 4 + 4 LDS instructions.  It lives in slabs 0-3 of the hidden ring, dead since interval 13.)
+            u32x4* const stg = s_ring + wu * 256;
+            const int tb = m0 + wt3 * 64 + tt * 32;                 // first token of the block
+            const int wr_idx = i32 * 8, wr_sw = i32 & 7, rd_tok = lane >> 3, rd_p = lane & 7, rd_sw = rd_p ^ (rd_tok & 7);
+            auto through_lds = [&](const u32x4 q0, const u32x4 q1, const u32x4 q2, const u32x4 q3, u32x4* out_rows /* 16-byte pieces, row = DOUT / 4 */) {
+                stg[wr_idx + ((4 * h + 0) ^ wr_sw)] = q0;
+                stg[wr_idx + ((4 * h + 1) ^ wr_sw)] = q1;
+                stg[wr_idx + ((4 * h + 2) ^ wr_sw)] = q2;
+                stg[wr_idx + ((4 * h + 3) ^ wr_sw)] = q3;
 #pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx)
-                    if (tq + sidx < p.T)
-                        *reinterpret_cast<u32x4*>(p.X + (long long)(tq + sidx) * DOUT + fb + 4 * ql) = sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3;
-            }
+                for (int it = 0; it < 4; ++it) {
+                    const int tok = rd_tok + 8 * it;
+                    const u32x4 v = stg[tok * 8 + rd_sw];
+                    if (tb + tok < p.T) out_rows[(long long)(tb + tok) * (DOUT / 4) + (wf3 * 64 + ft * 32) / 4 + rd_p] = v;
+                }
+            };
+            through_lds(__builtin_bit_cast(u32x4, f32x4{w[0], w[1], w[2], w[3]}), __builtin_bit_cast(u32x4, f32x4{w[4], w[5], w[6], w[7]}),
+                        __builtin_bit_cast(u32x4, f32x4{w[8], w[9], w[10], w[11]}), __builtin_bit_cast(u32x4, f32x4{w[12], w[13], w[14], w[15]}),
+                        reinterpret_cast<u32x4*>(p.X));
             {
                 const f32x8 g0 = {w[0], w[1], w[2], w[3], w[4], w[5], w[6], w[7]};
                 const f32x8 g1 = {w[8], w[9], w[10], w[11], w[12], w[13], w[14], w[15]};
                 f16x8 hi0, lo0, hi1, lo1;
                 split8(g0, hi0, lo0);
                 split8(g1, hi1, lo1);
-                u32x4 q0 = __builtin_bit_cast(u32x4, hi0), q1 = __builtin_bit_cast(u32x4, lo0);
-                u32x4 q2 = __builtin_bit_cast(u32x4, hi1), q3 = __builtin_bit_cast(u32x4, lo1);
-                quad_transpose(q0, q1, q2, q3, ql);
-                u32x4* ob = reinterpret_cast<u32x4*>(p.XS);
-#pragma unroll
-                for (int sidx = 0; sidx < 4; ++sidx)
-                    if (tq + sidx < p.T)
-                        ob[(((long long)(tq + sidx) * DOUT + fb) >> 2) + ql] = sidx == 0 ? q0 : sidx == 1 ? q1 : sidx == 2 ? q2 : q3;
+                through_lds(__builtin_bit_cast(u32x4, hi0), __builtin_bit_cast(u32x4, lo0), __builtin_bit_cast(u32x4, hi1), __builtin_bit_cast(u32x4, lo1),
+                            reinterpret_cast<u32x4*>(p.XS));
             }
         }
     }
