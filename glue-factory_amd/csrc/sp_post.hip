@@ -294,17 +294,48 @@ __global__ __launch_bounds__(SEL_THREADS) void select_kernel(const DetectArgs p)
     __syncthreads();
 
     // bitonic sort, descending, P elements
-    for (int k = 2; k <= P; k <<= 1) {
-        for (int j = k >> 1; j > 0; j >>= 1) {
-            for (int i = tid; i < P; i += SEL_THREADS) {
-                const int ixj = i ^ j;
-                if (ixj > i) {
-                    const unsigned long long a = s_keys[i], c = s_keys[ixj];
-                    const bool desc = ((i & k) == 0);
-                    if (desc ? (a < c) : (a > c)) { s_keys[i] = c; s_keys[ixj] = a; }
+    if (P <= SEL_THREADS) {
+        // One key per thread, in a register (round 4).  Of the log2(P) (log2(P) + 1) / 2 compare-exchange stages (55 at P = 1024) only those
+        // with a partner distance >= 64 cross a wave: they go through LDS, alternating between two halves of s_keys so that one barrier
+        // per stage suffices (10 at P = 1024); the others are two 32-bit wave shuffles.  Was: every stage an LDS round trip + barrier.
+        // Element i keeps the larger key of the pair iff it is the lower index of a descending pair or the upper one of an ascending pair.
+        unsigned long long v = s_keys[tid < P ? tid : 0];
+        int buf = 0;
+        __syncthreads();
+        for (int k = 2; k <= P; k <<= 1) {
+            const bool desc = ((tid & k) == 0);
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                unsigned long long pv;
+                if (j >= 64) {
+                    buf ^= 1;
+                    s_keys[buf * (SEL_MAXK / 2) + tid] = v;
+                    __syncthreads();
+                    pv = s_keys[buf * (SEL_MAXK / 2) + (tid ^ j)];
+                } else {
+                    const unsigned lo = __shfl_xor((unsigned)v, j), hi = __shfl_xor((unsigned)(v >> 32), j);
+                    pv = ((unsigned long long)hi << 32) | lo;
                 }
+                const bool lower = (tid & j) == 0;
+                const bool want_max = lower == desc;
+                v = want_max ? (v > pv ? v : pv) : (v < pv ? v : pv);
             }
-            __syncthreads();
+        }
+        __syncthreads();  // the last readers of either half are done
+        if (tid < P) s_keys[tid] = v;
+        __syncthreads();
+    } else {
+        for (int k = 2; k <= P; k <<= 1) {
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                for (int i = tid; i < P; i += SEL_THREADS) {
+                    const int ixj = i ^ j;
+                    if (ixj > i) {
+                        const unsigned long long a = s_keys[i], c = s_keys[ixj];
+                        const bool desc = ((i & k) == 0);
+                        if (desc ? (a < c) : (a > c)) { s_keys[i] = c; s_keys[ixj] = a; }
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
 
