@@ -40,7 +40,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel(unsigned long long* cy
 
 // Ping-pong: waves 0-3 (one per SIMD) run a BURST of MFMAs while waves 4-7 (their SIMD partners) issue NREAD ds_read_b128, NWRITE ds_write_b128
 // and NDMA LDS-DMA requests and wait for them; a barrier; roles swap; a barrier.  Cycles per SLOT (one burst of a SIMD): BURST x 32 = the pipe never idles.
-template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO, int BIGLDS = 0>
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO, int BIGLDS = 0, int DEP = 0, int XBAR = 0>
 __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycles, float* sink, int iters, const float* src) {
     __shared__ float lds[BIGLDS ? 36 * 1024 : 8 * 4096];  // BIGLDS: 144 KB, one workgroup per CU by LDS as in ffn_f16.hip
     for (int i = threadIdx.x; i < 8 * 4096; i += 512) lds[i] = i * 0.001f;
@@ -71,18 +71,28 @@ __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycle
     auto burst = [&]() {
         if (SETPRIO) asm volatile("s_setprio 2" ::: "memory");
 #pragma unroll
-        for (int g = 0; g < BURST; ++g) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a), "v"(b));
+        for (int g = 0; g < BURST; ++g) {
+            if (DEP) asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(ld[g & 7]), "v"(ld[(g + 3) & 7]));  // operands = what the memory phase read
+            else asm volatile("v_mfma_f32_32x32x16_f16 %0, %1, %2, %0" : "+v"(acc[g & 3]) : "v"(a), "v"(b));
+        }
         if (SETPRIO) asm volatile("s_setprio 0" ::: "memory");
+        if (XBAR) {  // the DMA requests of the real kernel: issued behind the burst, waited for one burst later (in flight across two barriers)
+#pragma unroll
+            for (int i = 0; i < NDMA; ++i)
+                asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"((unsigned)(((blockIdx.x & 15) * 8 + (i & 7)) * 1024 + (threadIdx.x & 63) * 16)), "s"(rsrc), "s"(m0v + i * 1024) : "memory");
+            asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA) : "memory");
+        }
     };
     auto mem = [&](int it) {
 #pragma unroll
-        for (int i = 0; i < NDMA; ++i)
+        for (int i = 0; i < (XBAR ? 0 : NDMA); ++i)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"((unsigned)(((blockIdx.x & 15) * 8 + ((it + i) & 7)) * 1024 + (threadIdx.x & 63) * 16)), "s"(rsrc), "s"(m0v + i * 1024) : "memory");
 #pragma unroll
         for (int i = 0; i < NREAD; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld[i & 7]) : "v"(laddr), "n"((i & 7) * 1024) : "memory");
 #pragma unroll
         for (int i = 0; i < NWRITE; ++i) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(laddr), "v"(ld[i & 7]), "n"(8192 + 4096) : "memory");
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        if (XBAR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
     for (int it = 0; it < iters; ++it) {
         if (grp == 0) { burst(); __builtin_amdgcn_s_barrier(); mem(it); __builtin_amdgcn_s_barrier(); }
@@ -96,7 +106,7 @@ __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycle
     if (s == 12345.678f) sink[threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
-template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO = 0, int BIGLDS = 0>
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO = 0, int BIGLDS = 0, int DEP = 0, int XBAR = 0>
 static double run_pp(int iters) {
     unsigned long long* d;
     float* sink;
@@ -104,7 +114,7 @@ static double run_pp(int iters) {
     if (!src) { hipMalloc(&src, 16 * 8 * 1024 + 4096); hipMemset(src, 0, 16 * 8 * 1024 + 4096); }
     hipMalloc(&d, 256 * 8 * 8);
     hipMalloc(&sink, 4096);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((pingpong_kernel<BURST, NREAD, NWRITE, NDMA, SETPRIO, BIGLDS>), dim3(256), dim3(512), 0, 0, d, sink, iters, src);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((pingpong_kernel<BURST, NREAD, NWRITE, NDMA, SETPRIO, BIGLDS, DEP, XBAR>), dim3(256), dim3(512), 0, 0, d, sink, iters, src);
     std::vector<unsigned long long> h(256 * 8);
     hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
     hipFree(d);
@@ -148,6 +158,10 @@ int main() {
     printf("  burst 24, partner 12 reads + 5 DMA:             %6.1f (ideal 768)\n", run_pp<24, 12, 0, 5>(it));
     printf("  burst 24, partner 16 reads + 8 writes + 4 DMA:  %6.1f\n", run_pp<24, 16, 8, 4>(it));
     printf("  burst 24, partner 16 reads (+ 8 writes), no DMA:  %6.1f %6.1f; with a 144 KB LDS allocation: %6.1f %6.1f\n", run_pp<24, 16, 0, 0>(it), run_pp<24, 16, 8, 0>(it), run_pp<24, 16, 0, 0, 0, 1>(it), run_pp<24, 16, 8, 0, 0, 1>(it));
+    printf("  burst 24, partner 16 reads: MFMA operands = the registers those reads load: %6.1f; + 4 DMA requests behind the burst, waited one burst later: %6.1f; both + 8 writes: %6.1f\n",
+           run_pp<24, 16, 0, 0, 0, 1, 1, 0>(it), run_pp<24, 16, 0, 4, 0, 1, 1, 1>(it), run_pp<24, 16, 8, 4, 0, 1, 1, 1>(it));
+    printf("  the same three, 100 x longer (~0.2 s each: sustained power): %6.1f %6.1f %6.1f; pure MFMA, two waves per SIMD, barrier every 24, 100 x longer: %5.2f cycles per MFMA\n",
+           run_pp<24, 16, 0, 0, 0, 1, 1, 0>(100 * it), run_pp<24, 16, 0, 4, 0, 1, 1, 1>(100 * it), run_pp<24, 16, 8, 4, 0, 1, 1, 1>(100 * it), run<4, 8, 24, 1>(100 * it));
     hipError_t e = hipDeviceSynchronize();
     printf("status %s\n", hipGetErrorString(e));
     return e != hipSuccess;
