@@ -40,7 +40,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel(unsigned long long* cy
 
 // Ping-pong: waves 0-3 (one per SIMD) run a BURST of MFMAs while waves 4-7 (their SIMD partners) issue NREAD ds_read_b128, NWRITE ds_write_b128
 // and NDMA LDS-DMA requests and wait for them; a barrier; roles swap; a barrier.  Cycles per SLOT (one burst of a SIMD): BURST x 32 = the pipe never idles.
-template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO, int BIGLDS = 0, int DEP = 0, int XBAR = 0>
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO, int BIGLDS = 0, int DEP = 0, int XBAR = 0, int REAL = 0>
 __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycles, float* sink, int iters, const float* src) {
     __shared__ float lds[BIGLDS ? 36 * 1024 : 8 * 4096];  // BIGLDS: 144 KB, one workgroup per CU by LDS as in ffn_f16.hip
     for (int i = threadIdx.x; i < 8 * 4096; i += 512) lds[i] = i * 0.001f;
@@ -87,10 +87,16 @@ __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycle
 #pragma unroll
         for (int i = 0; i < (XBAR ? 0 : NDMA); ++i)
             asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, 0 offen lds" ::"v"((unsigned)(((blockIdx.x & 15) * 8 + ((it + i) & 7)) * 1024 + (threadIdx.x & 63) * 16)), "s"(rsrc), "s"(m0v + i * 1024) : "memory");
+        if (REAL) {  // the kernel's addressing: 64-byte rows, the lane's 16-byte piece XOR-swizzled, a different 16 KB region of a 128 KB ring every slot
+            const unsigned i32 = threadIdx.x & 31, hh = (threadIdx.x >> 5) & 1;
+            const unsigned ra = (unsigned)(size_t)(__attribute__((address_space(3))) float*)lds + (i32 * 4 + ((2 * hh) ^ ((i32 >> 2) & 3))) * 16 + (it & 7) * 16384;
+#pragma unroll
+            for (int i = 0; i < NREAD; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld[i & 7]) : "v"(ra), "n"((i & 7) * 2048 + (i >> 3) * 16) : "memory");
+        } else
 #pragma unroll
         for (int i = 0; i < NREAD; ++i) asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(ld[i & 7]) : "v"(laddr), "n"((i & 7) * 1024) : "memory");
 #pragma unroll
-        for (int i = 0; i < NWRITE; ++i) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(laddr), "v"(ld[i & 7]), "n"(8192 + 4096) : "memory");
+        for (int i = 0; i < ((REAL && (wave & 3) != (it & 3)) ? 0 : NWRITE); ++i) asm volatile("ds_write_b128 %0, %1 offset:%2" ::"v"(laddr), "v"(ld[i & 7]), "n"(8192 + 4096) : "memory");  // REAL: one writer of four per slot
         if (XBAR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
@@ -106,7 +112,7 @@ __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycle
     if (s == 12345.678f) sink[threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
-template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO = 0, int BIGLDS = 0, int DEP = 0, int XBAR = 0>
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO = 0, int BIGLDS = 0, int DEP = 0, int XBAR = 0, int REAL = 0>
 static double run_pp(int iters) {
     unsigned long long* d;
     float* sink;
@@ -114,7 +120,7 @@ static double run_pp(int iters) {
     if (!src) { hipMalloc(&src, 16 * 8 * 1024 + 4096); hipMemset(src, 0, 16 * 8 * 1024 + 4096); }
     hipMalloc(&d, 256 * 8 * 8);
     hipMalloc(&sink, 4096);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((pingpong_kernel<BURST, NREAD, NWRITE, NDMA, SETPRIO, BIGLDS, DEP, XBAR>), dim3(256), dim3(512), 0, 0, d, sink, iters, src);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((pingpong_kernel<BURST, NREAD, NWRITE, NDMA, SETPRIO, BIGLDS, DEP, XBAR, REAL>), dim3(256), dim3(512), 0, 0, d, sink, iters, src);
     std::vector<unsigned long long> h(256 * 8);
     hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
     hipFree(d);
@@ -162,6 +168,7 @@ int main() {
            run_pp<24, 16, 0, 0, 0, 1, 1, 0>(it), run_pp<24, 16, 0, 4, 0, 1, 1, 1>(it), run_pp<24, 16, 8, 4, 0, 1, 1, 1>(it));
     printf("  the same three, 100 x longer (~0.2 s each: sustained power): %6.1f %6.1f %6.1f; pure MFMA, two waves per SIMD, barrier every 24, 100 x longer: %5.2f cycles per MFMA\n",
            run_pp<24, 16, 0, 0, 0, 1, 1, 0>(100 * it), run_pp<24, 16, 0, 4, 0, 1, 1, 1>(100 * it), run_pp<24, 16, 8, 4, 0, 1, 1, 1>(100 * it), run<4, 8, 24, 1>(100 * it));
+    printf("  ... + the kernel's LDS addressing (swizzled 64-byte rows, a different 16 KB of a 128 KB ring every slot) and one writer wave of four: %6.1f\n", run_pp<24, 16, 8, 4, 0, 1, 1, 1, 1>(it));
     hipError_t e = hipDeviceSynchronize();
     printf("status %s\n", hipGetErrorString(e));
     return e != hipSuccess;
