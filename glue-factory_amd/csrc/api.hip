@@ -1089,21 +1089,21 @@ static int lg_run(mg_handle h, const mg_lg_conf* conf, const float* kpts0, const
     float* ST = h->buf("lg.stats", 6 * Tin + 16);
     if (!X || !QKV || !CTX || !MSG || !HID || !ENC || !SIM || !Z || !ST) return fail(MG_ERR_HIP, "workspace allocation failed");
 
-    HIPCHK(hipMemcpyAsync(X, desc0, T0_in * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(hipMemcpyAsync(X + T0_in * 256, desc1, T1_in * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    const bool f16 = h->precision == MG_PREC_F16X3;
+    float* XS = nullptr;
+    if (f16) {  // descriptors -> the residual stream and its SH8 copy in one pass
+        XS = h->buf("lg.xs", Tin * 256);
+        if (!XS) return fail(MG_ERR_HIP, "workspace allocation failed");
+        launch_copy2_to_sh8(desc0, (long long)T0_in * 256, desc1, (long long)T1_in * 256, X, XS, s);
+    } else {
+        HIPCHK(hipMemcpyAsync(X, desc0, T0_in * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemcpyAsync(X + T0_in * 256, desc1, T1_in * 256 * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     {
         ProfScope ps(h, s, "lg.posenc");
         launch_posenc(kpts0, kpts1, size0, size1, h->Wr, B, M, N, ENC, s);
     }
     if (int rc = tap_copy(h, "lg.enc", ENC, Tin * 64, s)) return rc;
-
-    const bool f16 = h->precision == MG_PREC_F16X3;
-    float* XS = nullptr;
-    if (f16) {
-        XS = h->buf("lg.xs", Tin * 256);
-        if (!XS) return fail(MG_ERR_HIP, "workspace allocation failed");
-        launch_to_sh8(X, XS, (long long)Tin * 256, 1.f, s);
-    }
     // current token counts: only the adaptive variant changes them (point pruning)
     int Mc = M, Nc = N;
     size_t T0 = T0_in, T = Tin;

@@ -377,6 +377,24 @@ __global__ __launch_bounds__(256) void to_sh8_kernel(const float* __restrict__ i
     o[1] = lo;
 }
 
+// Entry of the LightGlue residual stream in f16x3 mode: the two descriptor sets -> the fp32 stream X and its SH8 copy, in ONE pass
+// (round 4; was two device copies and a conversion: 268 MB moved instead of 201, three launches instead of one)
+__global__ __launch_bounds__(256) void copy2_to_sh8_kernel(const float* __restrict__ in0, long long groups0, const float* __restrict__ in1, long long groups,
+                                                           float* __restrict__ x, void* __restrict__ out) {
+    const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (g >= groups) return;
+    const float* in = g < groups0 ? in0 + g * 8 : in1 + (g - groups0) * 8;
+    const f32x4 a = *reinterpret_cast<const f32x4*>(in), b = *reinterpret_cast<const f32x4*>(in + 4);
+    *reinterpret_cast<f32x4*>(x + g * 8) = a;
+    *reinterpret_cast<f32x4*>(x + g * 8 + 4) = b;
+    const f32x8 v = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+    f16x8 hi, lo;
+    split8(v, hi, lo);
+    f16x8* o = reinterpret_cast<f16x8*>(out) + g * 2;
+    o[0] = hi;
+    o[1] = lo;
+}
+
 // SH8 rows -> fp32 rows (test entries only)
 __global__ __launch_bounds__(256) void from_sh8_kernel(const void* __restrict__ in, float* __restrict__ out, long long groups) {
     const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -428,6 +446,11 @@ void launch_gemm_f16x3(const GemmF16Args& a0, hipStream_t s) {
 void launch_to_sh8(const float* in, void* out, long long elems, float scale, hipStream_t s) {
     const long long groups = elems / 8;
     hipLaunchKernelGGL(to_sh8_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, in, out, groups, scale);
+}
+
+void launch_copy2_to_sh8(const float* in0, long long elems0, const float* in1, long long elems1, float* x, void* out, hipStream_t s) {
+    const long long groups0 = elems0 / 8, groups = groups0 + elems1 / 8;
+    if (groups > 0) hipLaunchKernelGGL(copy2_to_sh8_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, in0, groups0, in1, groups, x, out);
 }
 
 void launch_from_sh8(const void* in, float* out, long long elems, hipStream_t s) {

@@ -120,6 +120,7 @@ void launch_gemm_f16x3(const GemmF16Args& a, hipStream_t s);   // tries launch_g
 bool launch_gemm_ws_f16x3(const GemmF16Args& a, hipStream_t s); // gemm_ws_f16.hip: K = 256, SH8 output, bias / rotary / scale only; false = not taken
 void launch_to_sh8(const float* in, void* out, long long elems, float scale, hipStream_t s);  // SH8(in * scale)
 void launch_from_sh8(const void* in, float* out, long long elems, hipStream_t s);          // hi + lo back to fp32
+void launch_copy2_to_sh8(const float* in0, long long elems0, const float* in1, long long elems1, float* x, void* out, hipStream_t s);  // x = [in0 | in1], out = SH8(x)
 
 // ---- ffn_f16.hip : x += W3 . act(W0f . [x | ctx] + b0) + b3 in one kernel (f16x3 mode) ------------------------------
 struct FfnF16Args {
