@@ -40,7 +40,7 @@ __global__ __launch_bounds__(WAVES * 64) void pair_kernel(unsigned long long* cy
 
 // Ping-pong: waves 0-3 (one per SIMD) run a BURST of MFMAs while waves 4-7 (their SIMD partners) issue NREAD ds_read_b128, NWRITE ds_write_b128
 // and NDMA LDS-DMA requests and wait for them; a barrier; roles swap; a barrier.  Cycles per SLOT (one burst of a SIMD): BURST x 32 = the pipe never idles.
-template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO, int BIGLDS = 0, int DEP = 0, int XBAR = 0, int REAL = 0>
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO, int BIGLDS = 0, int DEP = 0, int XBAR = 0, int REAL = 0, int UNR = 1>
 __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycles, float* sink, int iters, const float* src) {
     __shared__ float lds[BIGLDS ? 36 * 1024 : 8 * 4096];  // BIGLDS: 144 KB, one workgroup per CU by LDS as in ffn_f16.hip
     for (int i = threadIdx.x; i < 8 * 4096; i += 512) lds[i] = i * 0.001f;
@@ -100,9 +100,21 @@ __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycle
         if (XBAR) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     };
-    for (int it = 0; it < iters; ++it) {
-        if (grp == 0) { burst(); __builtin_amdgcn_s_barrier(); mem(it); __builtin_amdgcn_s_barrier(); }
-        else { mem(it); __builtin_amdgcn_s_barrier(); burst(); __builtin_amdgcn_s_barrier(); }
+    if (UNR == 1) {
+        for (int it = 0; it < iters; ++it) {
+            if (grp == 0) { burst(); __builtin_amdgcn_s_barrier(); mem(it); __builtin_amdgcn_s_barrier(); }
+            else { mem(it); __builtin_amdgcn_s_barrier(); burst(); __builtin_amdgcn_s_barrier(); }
+        }
+    } else {  // straight-line code as in the kernel: UNR slot pairs per group, one copy per group, looped
+        for (int it0 = 0; it0 < iters; it0 += UNR) {
+            if (grp == 0) {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) { burst(); __builtin_amdgcn_s_barrier(); mem(it0 + u); __builtin_amdgcn_s_barrier(); }
+            } else {
+#pragma unroll
+                for (int u = 0; u < UNR; ++u) { mem(it0 + u); __builtin_amdgcn_s_barrier(); burst(); __builtin_amdgcn_s_barrier(); }
+            }
+        }
     }
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t1)::"memory");
     float s = 0.f;
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(512) void pingpong_kernel(unsigned long long* cycle
     if (s == 12345.678f) sink[threadIdx.x] = s;
     if ((threadIdx.x & 63) == 0) cycles[blockIdx.x * 8 + (threadIdx.x >> 6)] = t1 - t0;
 }
-template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO = 0, int BIGLDS = 0, int DEP = 0, int XBAR = 0, int REAL = 0>
+template <int BURST, int NREAD, int NWRITE, int NDMA, int SETPRIO = 0, int BIGLDS = 0, int DEP = 0, int XBAR = 0, int REAL = 0, int UNR = 1>
 static double run_pp(int iters) {
     unsigned long long* d;
     float* sink;
@@ -120,7 +132,7 @@ static double run_pp(int iters) {
     if (!src) { hipMalloc(&src, 16 * 8 * 1024 + 4096); hipMemset(src, 0, 16 * 8 * 1024 + 4096); }
     hipMalloc(&d, 256 * 8 * 8);
     hipMalloc(&sink, 4096);
-    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((pingpong_kernel<BURST, NREAD, NWRITE, NDMA, SETPRIO, BIGLDS, DEP, XBAR, REAL>), dim3(256), dim3(512), 0, 0, d, sink, iters, src);
+    for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL((pingpong_kernel<BURST, NREAD, NWRITE, NDMA, SETPRIO, BIGLDS, DEP, XBAR, REAL, UNR>), dim3(256), dim3(512), 0, 0, d, sink, iters, src);
     std::vector<unsigned long long> h(256 * 8);
     hipMemcpy(h.data(), d, h.size() * 8, hipMemcpyDeviceToHost);
     hipFree(d);
@@ -169,6 +181,7 @@ int main() {
     printf("  the same three, 100 x longer (~0.2 s each: sustained power): %6.1f %6.1f %6.1f; pure MFMA, two waves per SIMD, barrier every 24, 100 x longer: %5.2f cycles per MFMA\n",
            run_pp<24, 16, 0, 0, 0, 1, 1, 0>(100 * it), run_pp<24, 16, 0, 4, 0, 1, 1, 1>(100 * it), run_pp<24, 16, 8, 4, 0, 1, 1, 1>(100 * it), run<4, 8, 24, 1>(100 * it));
     printf("  ... + the kernel's LDS addressing (swizzled 64-byte rows, a different 16 KB of a 128 KB ring every slot) and one writer wave of four: %6.1f\n", run_pp<24, 16, 8, 4, 0, 1, 1, 1, 1>(it));
+    printf("  burst 24, partner idle, as straight-line code of 16 slot pairs per group (the kernel's form) instead of a loop: %6.1f; with 16 reads: %6.1f\n", run_pp<24, 0, 0, 0, 0, 1, 0, 0, 0, 16>(it), run_pp<24, 16, 0, 0, 0, 1, 1, 0, 0, 16>(it));
     hipError_t e = hipDeviceSynchronize();
     printf("status %s\n", hipGetErrorString(e));
     return e != hipSuccess;
