@@ -27,7 +27,8 @@
 //            64 (j%8) + 16 (j/8) + 8a + 4h + e; W3 is tiled in that order at upload (api.hip: kperm).  Same pipeline as
 //            phase 1 (W3 stages by LDS-DMA, fragments of k-step k+1 read under the MFMAs of k-step k); the residual rows
 //            are fetched under the last eight k-steps, when the hidden block's registers are free.
-//   epilogue as in gemm_f16.hip: + b3, + residual, fp32 row and its SH8 copy, quad-transposed full-line stores.
+//   epilogue + b3, + residual, fp32 row and its SH8 copy; the lane's 64-byte pieces go through a wave-private LDS image and leave as
+//            full 128-byte lines (round 4; the quad transposes in registers of gemm_f16.hip cost 1 175 VALU instructions per wave here).
 #include "common.h"
 #include "kernels.h"
 
